@@ -1,0 +1,573 @@
+// mi_rt.cpp — host runtime behind the C ABI of include/mi_rt.h (libmi_rt.so).
+//
+//   * scene compiler: flattens the POD description of the reference's Scene.objects
+//     into the device layout of pt_device.h, including the BVH of every StaticMesh with
+//     the REFERENCE's topology (geometry.rs:190-217: median split of the triangle index
+//     range, leaf i = triangle i, exact union boxes), emitted in DFS pre-order with skip
+//     links for the stackless traversal of pt_kernels.hip.
+//   * render entry points: whole image on one GPU (mi_render) and the device-pointer
+//     building blocks used with one process per GPU (tiles, un-permute, tone-map).
+//
+// There is no CPU implementation of the render path in this library: every entry
+// point that produces pixels launches HIP kernels and reports an error when it cannot.
+// Compiled with hipcc, -ffp-contract=off: the values hoisted out of the per-ray code
+// (e1, e2, r*r, normalize(e1 x e2), -1/density, albedo/PI, the triangle tangent, the
+// camera basis) are computed here with the same f32 operations, in the same order,
+// the reference performs per ray, so hoisting them does not change a single bit.
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/mi_rt.h"
+#include "pt_device.h"
+
+#pragma clang fp contract(off)
+
+namespace pt {
+hipError_t launch_megakernel(const K1Args& args, uint32_t n_blocks, bool lds, bool park, bool sig,
+                             size_t lds_bytes, hipStream_t stream);
+hipError_t launch_unpermute(const float* gathered, float* image, uint32_t width, uint32_t height, uint32_t tiles_x,
+                            uint32_t world, uint32_t tiles_padded, hipStream_t stream);
+hipError_t launch_sig_unpermute(const uint32_t* gathered, uint32_t* image, uint32_t width, uint32_t height,
+                                uint32_t tiles_x, uint32_t world, uint32_t tiles_padded, hipStream_t stream);
+hipError_t launch_tonemap(const float* image, uint8_t* out, uint32_t n_pixels, float inv_gamma, hipStream_t stream);
+}  // namespace pt
+
+using namespace pt;
+
+// ------------------------------------------------------------------ errors
+static thread_local std::string g_err;
+static int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    g_err = buf;
+    return code;
+}
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess) return fail(MI_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+// ------------------------------------------------------------------ host f32 math (reference order)
+namespace {
+struct h3 { float x, y, z; };
+inline h3 H3(float x, float y, float z) { h3 r = { x, y, z }; return r; }
+inline h3 H3p(const float* p) { return H3(p[0], p[1], p[2]); }
+inline h3 sub(h3 a, h3 b) { return H3(a.x - b.x, a.y - b.y, a.z - b.z); }
+inline h3 scale(h3 a, float s) { return H3(a.x * s, a.y * s, a.z * s); }
+inline float dot(h3 a, h3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+inline h3 cross(h3 a, h3 b) { return H3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+inline h3 normalize(h3 a) { return scale(a, 1.0f / sqrtf(dot(a, a))); }
+inline uint32_t lowbias32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x;
+}
+}  // namespace
+
+// ------------------------------------------------------------------ context
+struct mi_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;            // own stream for mi_render
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    bool ev_recorded = false;
+
+    // device scene
+    void* blob = nullptr; size_t blob_bytes = 0;
+    DScene S{};
+    bool have_scene = false;
+    uint32_t lds_bytes = 0;                  // bytes needed to stage nodes + tris, 0 = no meshes
+
+    // scratch for mi_render
+    float* d_compact = nullptr; size_t compact_bytes = 0;
+    float* d_image = nullptr;   size_t image_bytes = 0;
+    uint8_t* d_u8 = nullptr;    size_t u8_bytes = 0;
+    uint32_t* d_sigc = nullptr; size_t sigc_bytes = 0;
+    uint32_t* d_sigi = nullptr; size_t sigi_bytes = 0;
+};
+
+static int ensure(void** p, size_t* have, size_t want) {
+    if (*have >= want && *p) return MI_OK;
+    if (*p) { (void)hipFree(*p); *p = nullptr; *have = 0; }
+    hipError_t e = hipMalloc(p, want);
+    if (e != hipSuccess) return fail(MI_ERR_OOM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+    *have = want;
+    return MI_OK;
+}
+
+extern "C" int mi_abi_version(void) { return MI_RT_ABI_VERSION; }
+extern "C" const char* mi_last_error(void) { return g_err.c_str(); }
+
+extern "C" int mi_ctx_create(int device, mi_ctx** out) {
+    if (!out) return fail(MI_ERR_INVALID, "mi_ctx_create: out is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(MI_ERR_NO_DEVICE, "no HIP device available (%s); the render path has no CPU fallback",
+                    e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    if (device < 0 || device >= n) return fail(MI_ERR_INVALID, "device %d out of range (have %d)", device, n);
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(MI_ERR_NO_DEVICE, "device %d is %s; this library carries gfx950 (MI355X) code only", device, prop.gcnArchName);
+    mi_ctx* c = new mi_ctx();
+    c->device = device;
+    HIP_TRY(hipStreamCreate(&c->stream));
+    HIP_TRY(hipEventCreate(&c->ev_start));
+    HIP_TRY(hipEventCreate(&c->ev_stop));
+    *out = c;
+    return MI_OK;
+}
+
+extern "C" void mi_ctx_destroy(mi_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    if (c->blob) (void)hipFree(c->blob);
+    if (c->d_compact) (void)hipFree(c->d_compact);
+    if (c->d_image) (void)hipFree(c->d_image);
+    if (c->d_u8) (void)hipFree(c->d_u8);
+    if (c->d_sigc) (void)hipFree(c->d_sigc);
+    if (c->d_sigi) (void)hipFree(c->d_sigi);
+    if (c->ev_start) (void)hipEventDestroy(c->ev_start);
+    if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+// ------------------------------------------------------------------ scene compiler
+namespace {
+
+struct Box { h3 mn, mx; };
+
+// IndexedTriangle::bounding_box geometry.rs:367-381
+Box tri_box(h3 a, h3 b, h3 c) {
+    Box r;
+    r.mn = H3(fminf(a.x, fminf(b.x, c.x)), fminf(a.y, fminf(b.y, c.y)), fminf(a.z, fminf(b.z, c.z)));
+    r.mx = H3(fmaxf(a.x, fmaxf(b.x, c.x)), fmaxf(a.y, fmaxf(b.y, c.y)), fmaxf(a.z, fmaxf(b.z, c.z)));
+    return r;
+}
+// AABB::aabb_surrounding geometry.rs:28-41
+Box surround(const Box& a, const Box& b) {
+    Box r;
+    r.mn = H3(fminf(a.mn.x, b.mn.x), fminf(a.mn.y, b.mn.y), fminf(a.mn.z, b.mn.z));
+    r.mx = H3(fmaxf(a.mx.x, b.mx.x), fmaxf(a.mx.y, b.mx.y), fmaxf(a.mx.z, b.mx.z));
+    return r;
+}
+
+struct MeshCompiler {
+    const mi_mesh* m;
+    std::vector<float>* nodes;     // 8 floats per node
+    int base;                      // index of this mesh's root in the node pool
+
+    h3 vpos(int tri, int corner) const { return H3p(&m->positions[3 * (size_t)m->indices[3 * (size_t)tri + corner]]); }
+
+    // StaticMesh::build_bvh_helper geometry.rs:190-217, emitted in DFS pre-order.
+    // The reference's random-axis sort (:200-207) only permutes a scratch vector whose
+    // entries are never read back (the leaf is built from `idx: start`, :194), so the
+    // tree is this index-range median split whatever the RNG does.
+    Box build(int start, int end) {
+        int me = (int)(nodes->size() / 8);
+        nodes->resize(nodes->size() + 8);
+        Box box;
+        int tri = -1;
+        if (end - start == 1) {                                         // :192
+            box = tri_box(vpos(start, 0), vpos(start, 1), vpos(start, 2));   // :195
+            tri = start;                                                // :194
+        } else {
+            int mid = start + (end - start) / 2;                        // :209
+            Box l = build(start, mid);                                  // :210
+            Box r = build(mid, end);                                    // :211
+            box = surround(l, r);                                       // :212
+        }
+        int skip = (int)(nodes->size() / 8);                            // first node after this subtree
+        float* n = &(*nodes)[(size_t)me * 8];
+        n[0] = box.mn.x; n[1] = box.mn.y; n[2] = box.mn.z; memcpy(&n[3], &skip, 4);
+        n[4] = box.mx.x; n[5] = box.mx.y; n[6] = box.mx.z; memcpy(&n[7], &tri, 4);
+        return box;
+    }
+};
+
+bool finite16(const float* m) { for (int i = 0; i < 16; i++) if (!std::isfinite(m[i])) return false; return true; }
+
+}  // namespace
+
+extern "C" int mi_scene_upload(mi_ctx* c, const mi_scene_desc* d) {
+    if (!c || !d) return fail(MI_ERR_INVALID, "mi_scene_upload: NULL argument");
+    if (d->n_objects < 0 || d->n_materials < 0 || d->n_meshes < 0 || d->n_textures < 0)
+        return fail(MI_ERR_INVALID, "negative count");
+    if (d->n_objects > 0 && !d->objects) return fail(MI_ERR_INVALID, "objects is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+
+    std::vector<DObject> objs((size_t)d->n_objects);
+    std::vector<DMaterial> mats((size_t)d->n_materials);
+    std::vector<DMesh> meshes((size_t)d->n_meshes);
+    std::vector<float> nodes, tris;
+    std::vector<DTriAttr> attrs;
+    std::vector<DTexture> texs((size_t)d->n_textures);
+    std::vector<uint8_t> texels;
+
+    const float PI = 3.14159265358979323846f;
+    for (int i = 0; i < d->n_materials; i++) {
+        const mi_material& s = d->materials[i];
+        if (s.kind < MI_MAT_LAMBERTIAN || s.kind > MI_MAT_ISOTROPIC) return fail(MI_ERR_INVALID, "material %d: bad kind %d", i, s.kind);
+        DMaterial& m = mats[(size_t)i];
+        memset(&m, 0, sizeof m);
+        m.kind = s.kind;
+        for (int k = 0; k < 3; k++) { m.albedo[k] = s.albedo[k]; m.emission[k] = s.emission[k]; m.albedo_over_pi[k] = s.albedo[k] / PI; }
+        if (s.kind == MI_MAT_DIELECTRIC) for (int k = 0; k < 3; k++) m.emission[k] = 0.0f;      // materials.rs:102
+        m.roughness = s.roughness; m.metallic = s.metallic; m.ior = s.idx_of_refraction;
+    }
+    auto mat_ok = [&](int id) { return id >= 0 && id < d->n_materials; };
+
+    for (int i = 0; i < d->n_textures; i++) {
+        const mi_texture& t = d->textures[i];
+        if (t.width <= 0 || t.height <= 0 || !t.rgb) return fail(MI_ERR_INVALID, "texture %d: bad size or NULL texels", i);
+        while (texels.size() % 16) texels.push_back(0);
+        texs[(size_t)i].offset = (uint32_t)texels.size();
+        texs[(size_t)i].width = t.width; texs[(size_t)i].height = t.height; texs[(size_t)i].pad = 0;
+        size_t nb = (size_t)t.width * t.height * 3;
+        texels.insert(texels.end(), t.rgb, t.rgb + nb);
+    }
+
+    // meshes: BVH + de-indexed triangle pools
+    for (int mi = 0; mi < d->n_meshes; mi++) {
+        const mi_mesh& s = d->meshes[mi];
+        if (!s.positions || !s.normals || !s.texcoords || !s.indices || s.n_triangles < 1 || s.n_vertices < 1)
+            return fail(MI_ERR_INVALID, "mesh %d: positions, normals, texcoords and indices are all required (geometry.rs:350,355)", mi);
+        for (size_t k = 0; k < 3 * (size_t)s.n_triangles; k++)
+            if (s.indices[k] >= (uint32_t)s.n_vertices) return fail(MI_ERR_INVALID, "mesh %d: index %u out of range", mi, s.indices[k]);
+        if (!finite16(s.transform) || !finite16(s.inv_transform)) return fail(MI_ERR_INVALID, "mesh %d: non-finite transform", mi);
+        if (s.material >= d->n_materials) return fail(MI_ERR_INVALID, "mesh %d: bad material", mi);
+        DMesh& M = meshes[(size_t)mi];
+        memset(&M, 0, sizeof M);
+        memcpy(M.transform, s.transform, sizeof M.transform);
+        memcpy(M.inv_transform, s.inv_transform, sizeof M.inv_transform);
+        M.material = s.material < 0 ? -1 : s.material;
+        for (int k = 0; k < 5; k++) {
+            if (s.textures[k] >= d->n_textures) return fail(MI_ERR_INVALID, "mesh %d: bad texture index", mi);
+            M.tex[k] = s.textures[k] < 0 ? -1 : s.textures[k];
+        }
+        M.object_index = -1;
+        M.node_begin = (int)(nodes.size() / 8);
+        M.tri_begin = (int)(tris.size() / 12);
+        M.n_tris = s.n_triangles;
+        MeshCompiler mc{ &s, &nodes, M.node_begin };
+        mc.build(0, s.n_triangles);                                     // geometry.rs:185
+        M.node_end = (int)(nodes.size() / 8);
+        // skip links are pool-absolute already (node indices are pool indices)
+        for (int t = 0; t < s.n_triangles; t++) {
+            uint32_t ia = s.indices[3 * (size_t)t], ib = s.indices[3 * (size_t)t + 1], ic = s.indices[3 * (size_t)t + 2];
+            h3 a = H3p(&s.positions[3 * (size_t)ia]), b = H3p(&s.positions[3 * (size_t)ib]), cc = H3p(&s.positions[3 * (size_t)ic]);
+            h3 e1 = sub(b, a), e2 = sub(cc, a);                         // geometry.rs:336-337
+            float rec[12] = { a.x, a.y, a.z, 0.0f, e1.x, e1.y, e1.z, 0.0f, e2.x, e2.y, e2.z, 0.0f };
+            tris.insert(tris.end(), rec, rec + 12);
+            DTriAttr A; memset(&A, 0, sizeof A);
+            memcpy(A.na, &s.normals[3 * (size_t)ia], 12); memcpy(A.nb, &s.normals[3 * (size_t)ib], 12); memcpy(A.nc, &s.normals[3 * (size_t)ic], 12);
+            memcpy(A.ta, &s.texcoords[2 * (size_t)ia], 8); memcpy(A.tb, &s.texcoords[2 * (size_t)ib], 8); memcpy(A.tc, &s.texcoords[2 * (size_t)ic], 8);
+            // StaticMesh::get_tangent geometry.rs:245-250
+            float u1 = A.ta[0], u2 = A.tb[0], u3 = A.tc[0], v1 = A.ta[1], v2 = A.tb[1], v3 = A.tc[1];
+            h3 num = sub(scale(sub(b, a), (v3 - v1)), scale(sub(cc, a), (v2 - v1)));
+            float den = (u2 - u1) * (v3 - v1) - (v2 - v1) * (u3 - u1);
+            A.tan[0] = num.x / den; A.tan[1] = num.y / den; A.tan[2] = num.z / den;
+            attrs.push_back(A);
+        }
+    }
+
+    // Scene.objects in order
+    for (int i = 0; i < d->n_objects; i++) {
+        const mi_object& o = d->objects[i];
+        DObject& D = objs[(size_t)i];
+        memset(&D, 0, sizeof D);
+        D.kind = o.kind;
+        switch (o.kind) {
+        case MI_OBJ_SPHERE: {
+            if (o.index < 0 || o.index >= d->n_spheres || !d->spheres) return fail(MI_ERR_INVALID, "object %d: bad sphere index", i);
+            const mi_sphere& s = d->spheres[o.index];
+            if (!mat_ok(s.material)) return fail(MI_ERR_INVALID, "object %d: bad material", i);
+            D.material = s.material;
+            D.f[0] = s.center[0]; D.f[1] = s.center[1]; D.f[2] = s.center[2]; D.f[3] = s.radius;
+            D.f[4] = s.radius * s.radius;                               // geometry.rs:400
+            break;
+        }
+        case MI_OBJ_TRIANGLE: {
+            if (o.index < 0 || o.index >= d->n_triangles || !d->triangles) return fail(MI_ERR_INVALID, "object %d: bad triangle index", i);
+            const mi_triangle& t = d->triangles[o.index];
+            if (!mat_ok(t.material)) return fail(MI_ERR_INVALID, "object %d: bad material", i);
+            D.material = t.material;
+            h3 a = H3p(t.a), e1 = sub(H3p(t.b), a), e2 = sub(H3p(t.c), a);      // geometry.rs:434-435
+            h3 n = normalize(cross(e1, e2));                                    // geometry.rs:449
+            D.f[0] = a.x; D.f[1] = a.y; D.f[2] = a.z;
+            D.f[3] = e1.x; D.f[4] = e1.y; D.f[5] = e1.z;
+            D.f[6] = e2.x; D.f[7] = e2.y; D.f[8] = e2.z;
+            D.f[9] = n.x; D.f[10] = n.y; D.f[11] = n.z;
+            break;
+        }
+        case MI_OBJ_PLANE: {
+            if (o.index < 0 || o.index >= d->n_planes || !d->planes) return fail(MI_ERR_INVALID, "object %d: bad plane index", i);
+            const mi_plane& p = d->planes[o.index];
+            if (!mat_ok(p.material)) return fail(MI_ERR_INVALID, "object %d: bad material", i);
+            D.material = p.material;
+            for (int k = 0; k < 3; k++) { D.f[k] = p.point[k]; D.f[3 + k] = p.normal[k]; }
+            break;
+        }
+        case MI_OBJ_VOLUME: {
+            if (o.index < 0 || o.index >= d->n_volumes || !d->volumes) return fail(MI_ERR_INVALID, "object %d: bad volume index", i);
+            const mi_volume& v = d->volumes[o.index];
+            if (!mat_ok(v.phase_material)) return fail(MI_ERR_INVALID, "object %d: bad phase material", i);
+            D.material = v.phase_material;
+            for (int k = 0; k < 3; k++) D.f[k] = v.boundary_center[k];
+            D.f[3] = v.boundary_radius;
+            D.f[4] = v.boundary_radius * v.boundary_radius;             // geometry.rs:400 via :505
+            D.f[5] = -1.0f / v.density;                                 // geometry.rs:517
+            break;
+        }
+        case MI_OBJ_MESH: {
+            if (o.index < 0 || o.index >= d->n_meshes) return fail(MI_ERR_INVALID, "object %d: bad mesh index", i);
+            if (meshes[(size_t)o.index].object_index >= 0)
+                return fail(MI_ERR_UNSUPPORTED, "object %d: a StaticMesh may appear once in Scene.objects", i);
+            meshes[(size_t)o.index].object_index = i;
+            D.ref = o.index; D.material = -1;
+            break;
+        }
+        default: return fail(MI_ERR_INVALID, "object %d: unknown kind %d", i, o.kind);
+        }
+    }
+    // meshes that are not referenced by Scene.objects are not part of the scene
+    std::vector<DMesh> live;
+    for (int i = 0; i < d->n_objects; i++)
+        if (objs[(size_t)i].kind == OBJ_MESH) { int r = objs[(size_t)i].ref; objs[(size_t)i].ref = (int)live.size(); live.push_back(meshes[(size_t)r]); }
+
+    // one blob: objects | materials | meshes | nodes | tris | attrs | textures | texels
+    auto align = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    size_t off_obj = 0;
+    size_t off_mat = align(off_obj + objs.size() * sizeof(DObject));
+    size_t off_mesh = align(off_mat + mats.size() * sizeof(DMaterial));
+    size_t off_nodes = align(off_mesh + live.size() * sizeof(DMesh));
+    size_t off_tris = align(off_nodes + nodes.size() * 4);
+    size_t off_attr = align(off_tris + tris.size() * 4);
+    size_t off_tex = align(off_attr + attrs.size() * sizeof(DTriAttr));
+    size_t off_texel = align(off_tex + texs.size() * sizeof(DTexture));
+    size_t total = align(off_texel + texels.size() + 16);
+    if (total > 0xffffffffull) return fail(MI_ERR_UNSUPPORTED, "scene larger than 4 GiB");
+    std::vector<uint8_t> host(total, 0);
+    auto put = [&](size_t off, const void* p, size_t n) { if (n) memcpy(host.data() + off, p, n); };
+    put(off_obj, objs.data(), objs.size() * sizeof(DObject));
+    put(off_mat, mats.data(), mats.size() * sizeof(DMaterial));
+    put(off_mesh, live.data(), live.size() * sizeof(DMesh));
+    put(off_nodes, nodes.data(), nodes.size() * 4);
+    put(off_tris, tris.data(), tris.size() * 4);
+    put(off_attr, attrs.data(), attrs.size() * sizeof(DTriAttr));
+    put(off_tex, texs.data(), texs.size() * sizeof(DTexture));
+    put(off_texel, texels.data(), texels.size());
+
+    if (c->blob) { (void)hipFree(c->blob); c->blob = nullptr; c->blob_bytes = 0; c->have_scene = false; }
+    hipError_t e = hipMalloc(&c->blob, total);
+    if (e != hipSuccess) return fail(MI_ERR_OOM, "hipMalloc(%zu) for the scene failed: %s", total, hipGetErrorString(e));
+    c->blob_bytes = total;
+    HIP_TRY(hipMemcpy(c->blob, host.data(), total, hipMemcpyHostToDevice));
+    uint8_t* b = (uint8_t*)c->blob;
+    c->S.objects = (const DObject*)(b + off_obj);
+    c->S.materials = (const DMaterial*)(b + off_mat);
+    c->S.meshes = (const DMesh*)(b + off_mesh);
+    c->S.nodes = (const float*)(b + off_nodes);
+    c->S.tris = (const float*)(b + off_tris);
+    c->S.triattr = (const DTriAttr*)(b + off_attr);
+    c->S.textures = (const DTexture*)(b + off_tex);
+    c->S.texels = (const uint8_t*)(b + off_texel);
+    c->S.n_objects = (int)objs.size();
+    c->S.n_meshes = (int)live.size();
+    c->S.n_nodes = (int)(nodes.size() / 8);
+    c->S.n_tris = (int)(tris.size() / 12);
+    c->lds_bytes = (uint32_t)((nodes.size() + tris.size()) * 4);
+    c->have_scene = true;
+    return MI_OK;
+}
+
+// ------------------------------------------------------------------ render
+static int check_camera(const mi_camera_desc* cam) {
+    if (!cam) return fail(MI_ERR_INVALID, "camera is NULL");
+    if (cam->projection_mode != MI_PROJ_PERSPECTIVE)
+        return fail(MI_ERR_UNSUPPORTED, "CameraProjectionMode::Orthographic is outside the accelerated path (tracing.rs:196,200)");
+    if (cam->shading_mode != MI_SHADE_PATHTRACE)
+        return fail(MI_ERR_UNSUPPORTED, "ShadingMode::Phong (debug shading, tracing.rs:277-297) is outside the accelerated path");
+    if (cam->path_samples != 1)
+        return fail(MI_ERR_UNSUPPORTED, "path_samples must be 1 on the GPU path (every configuration; tracing.rs:370)");
+    if (cam->screen_width == 0 || cam->screen_height == 0 || cam->screen_width > 32768 || cam->screen_height > 32768)
+        return fail(MI_ERR_INVALID, "bad image size %ux%u", cam->screen_width, cam->screen_height);
+    if (cam->aa_sample_count == 0) return fail(MI_ERR_INVALID, "aa_sample_count must be >= 1");
+    if ((uint32_t)sqrtf((float)cam->aa_sample_count) == 0) return fail(MI_ERR_INVALID, "aa_sample_count too small");
+    return MI_OK;
+}
+
+static void tile_counts(const mi_camera_desc* cam, int world, uint32_t* tx, uint32_t* ty, uint32_t* total, uint32_t* padded) {
+    *tx = (cam->screen_width + MI_TILE - 1) / MI_TILE;
+    *ty = (cam->screen_height + MI_TILE - 1) / MI_TILE;
+    *total = *tx * *ty;
+    *padded = (*total + (uint32_t)world - 1) / (uint32_t)world;
+}
+
+extern "C" int mi_compact_size(const mi_camera_desc* cam, int32_t world, uint32_t* tiles_total, uint32_t* tiles_padded) {
+    if (!cam || world < 1 || !tiles_total || !tiles_padded) return fail(MI_ERR_INVALID, "mi_compact_size: bad argument");
+    uint32_t tx, ty;
+    tile_counts(cam, world, &tx, &ty, tiles_total, tiles_padded);
+    return MI_OK;
+}
+
+static void make_camera(const mi_camera_desc* cam, DCamera* C) {
+    memset(C, 0, sizeof *C);
+    h3 view = H3p(cam->view_dir), up = H3p(cam->up);
+    h3 c0 = normalize(cross(view, up));                                 // tracing.rs:188
+    C->eye[0] = cam->eyepoint[0]; C->eye[1] = cam->eyepoint[1]; C->eye[2] = cam->eyepoint[2];
+    C->rot[0] = c0.x; C->rot[1] = c0.y; C->rot[2] = c0.z;
+    C->rot[3] = up.x; C->rot[4] = up.y; C->rot[5] = up.z;               // :189
+    C->rot[6] = -view.x; C->rot[7] = -view.y; C->rot[8] = -view.z;      // :190
+    C->pixel_size = 1.0f / (float)cam->screen_height;                   // :160
+    C->n = (float)cam->aa_sample_count;                                 // :162
+    C->rootn = sqrtf(C->n);                                             // :163
+    C->half_rootn = 0.5f * C->rootn;
+    C->half_n = 0.5f * C->n;
+    C->cx_base = -(0.5f * (float)cam->screen_width);                    // :178
+    C->cy_base = 0.5f + 0.5f * (float)cam->screen_height;               // :179
+    C->focal_length = cam->focal_length; C->focus_dist = cam->focus_dist; C->lens_radius = cam->lens_radius;
+    C->max_trace_dist = cam->max_trace_dist;
+    C->rootn_u = (uint32_t)C->rootn;                                    // :169 `rootn as u32`
+    C->spp = cam->aa_sample_count;
+    C->zone = (C->spp << __builtin_clz(C->spp)) - 1u;                   // rand 0.8.4 UniformInt::sample_single
+    C->path_depth = cam->path_depth;
+    C->width = cam->screen_width; C->height = cam->screen_height;
+}
+
+static int render_tiles(mi_ctx* c, const mi_camera_desc* cam, const mi_render_opts* o, float* d_compact,
+                        uint32_t* d_sig, hipStream_t stream, mi_stats* st) {
+    int rc = check_camera(cam);
+    if (rc != MI_OK) return rc;
+    if (!c->have_scene) return fail(MI_ERR_NO_SCENE, "no scene uploaded");
+    if (!o || o->world < 1 || o->rank < 0 || o->rank >= o->world) return fail(MI_ERR_INVALID, "bad rank/world");
+    if (!d_compact) return fail(MI_ERR_INVALID, "output buffer is NULL");
+    K1Args a;
+    a.S = c->S;
+    make_camera(cam, &a.C);
+    uint32_t tx, ty, total, padded;
+    tile_counts(cam, o->world, &tx, &ty, &total, &padded);
+    a.R.seed = o->seed; a.R.rank = o->rank; a.R.world = o->world;
+    a.R.tiles_x = tx; a.R.tiles_y = ty; a.R.tiles_total = total;
+    a.R.my_tiles = (total > (uint32_t)o->rank) ? (total - (uint32_t)o->rank + (uint32_t)o->world - 1) / (uint32_t)o->world : 0;
+    bool lds = c->S.n_meshes > 0 && c->lds_bytes <= 64u * 1024u;
+    a.R.lds_nodes = lds ? (uint32_t)c->S.n_nodes : 0;
+    a.R.lds_tris = lds ? (uint32_t)c->S.n_tris : 0;
+    a.seed_key = lowbias32(o->seed ^ 0x68e31da4u);
+    a.out = d_compact;
+    a.sig = (o->want_signature && d_sig) ? d_sig : nullptr;
+    int variant = o->variant == MI_VARIANT_DEFAULT ? MI_VARIANT_PARKED : o->variant;
+    if (variant != MI_VARIANT_SIMPLE && variant != MI_VARIANT_PARKED) return fail(MI_ERR_INVALID, "unknown variant %d", o->variant);
+    bool park = variant == MI_VARIANT_PARKED && c->S.n_meshes > 0;
+    uint32_t n_blocks = padded * (uint32_t)kBlocksPerTile;
+    HIP_TRY(hipEventRecord(c->ev_start, stream));
+    HIP_TRY(launch_megakernel(a, n_blocks, lds, park, a.sig != nullptr, c->lds_bytes, stream));
+    HIP_TRY(hipEventRecord(c->ev_stop, stream));
+    c->ev_recorded = true;
+    if (st) {
+        memset(st, 0, sizeof *st);
+        uint64_t pixels = 0;
+        for (uint32_t t = (uint32_t)o->rank; t < total; t += (uint32_t)o->world) {
+            uint32_t x0 = (t % tx) * MI_TILE, y0 = (t / tx) * MI_TILE;
+            uint32_t w = cam->screen_width - x0 < MI_TILE ? cam->screen_width - x0 : MI_TILE;
+            uint32_t h = cam->screen_height - y0 < MI_TILE ? cam->screen_height - y0 : MI_TILE;
+            pixels += (uint64_t)w * h;
+        }
+        st->pixels = pixels;
+        st->samples = pixels * cam->aa_sample_count;
+        st->tiles = a.R.my_tiles; st->tiles_padded = padded;
+        st->scene_bytes = (uint32_t)c->blob_bytes; st->scene_in_lds = lds ? 1u : 0u;
+    }
+    return MI_OK;
+}
+
+extern "C" int mi_render_tiles_device(mi_ctx* c, const mi_camera_desc* cam, const mi_render_opts* opts,
+                                      void* d_compact_f32, void* d_sig_u32, void* stream, mi_stats* stats) {
+    if (!c) return fail(MI_ERR_INVALID, "ctx is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    return render_tiles(c, cam, opts, (float*)d_compact_f32, (uint32_t*)d_sig_u32, (hipStream_t)stream, stats);
+}
+
+extern "C" int mi_unpermute_device(mi_ctx* c, const mi_camera_desc* cam, int32_t world, const void* d_gathered_f32,
+                                   void* d_image_f32, void* stream) {
+    if (!c || !cam || world < 1 || !d_gathered_f32 || !d_image_f32) return fail(MI_ERR_INVALID, "mi_unpermute_device: bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    uint32_t tx, ty, total, padded;
+    tile_counts(cam, world, &tx, &ty, &total, &padded);
+    HIP_TRY(launch_unpermute((const float*)d_gathered_f32, (float*)d_image_f32, cam->screen_width, cam->screen_height, tx,
+                             (uint32_t)world, padded, (hipStream_t)stream));
+    return MI_OK;
+}
+
+extern "C" int mi_tonemap_device(mi_ctx* c, const mi_camera_desc* cam, const void* d_image_f32, void* d_image_u8, void* stream) {
+    if (!c || !cam || !d_image_f32 || !d_image_u8) return fail(MI_ERR_INVALID, "mi_tonemap_device: bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(launch_tonemap((const float*)d_image_f32, (uint8_t*)d_image_u8, cam->screen_width * cam->screen_height,
+                           1.0f / cam->gamma, (hipStream_t)stream));                            // tracing.rs:254
+    return MI_OK;
+}
+
+extern "C" int mi_last_kernel_ms(mi_ctx* c, float* ms) {
+    if (!c || !ms) return fail(MI_ERR_INVALID, "mi_last_kernel_ms: bad argument");
+    if (!c->ev_recorded) return fail(MI_ERR_INVALID, "no kernel has been launched on this context");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipEventSynchronize(c->ev_stop));
+    HIP_TRY(hipEventElapsedTime(ms, c->ev_start, c->ev_stop));
+    return MI_OK;
+}
+
+extern "C" int mi_render(mi_ctx* c, const mi_camera_desc* cam, const mi_render_opts* opts, float* out_rgb_f32,
+                         uint8_t* out_rgb_u8, uint32_t* out_sig, mi_stats* stats) {
+    if (!c) return fail(MI_ERR_INVALID, "ctx is NULL");
+    if (!opts) return fail(MI_ERR_INVALID, "opts is NULL");
+    if (opts->rank != 0 || opts->world != 1) return fail(MI_ERR_INVALID, "mi_render renders a whole image: rank/world must be 0/1");
+    int rc = check_camera(cam);
+    if (rc != MI_OK) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    hipEvent_t t0, t1;
+    HIP_TRY(hipEventCreate(&t0)); HIP_TRY(hipEventCreate(&t1));
+    uint32_t tx, ty, total, padded;
+    tile_counts(cam, 1, &tx, &ty, &total, &padded);
+    size_t npix = (size_t)cam->screen_width * cam->screen_height;
+    size_t cbytes = (size_t)padded * kTilePixels * 3 * sizeof(float);
+    if ((rc = ensure((void**)&c->d_compact, &c->compact_bytes, cbytes)) != MI_OK) return rc;
+    if ((rc = ensure((void**)&c->d_image, &c->image_bytes, npix * 3 * sizeof(float))) != MI_OK) return rc;
+    bool want_sig = opts->want_signature && out_sig;
+    if (want_sig) {
+        if ((rc = ensure((void**)&c->d_sigc, &c->sigc_bytes, (size_t)padded * kTilePixels * 4)) != MI_OK) return rc;
+        if ((rc = ensure((void**)&c->d_sigi, &c->sigi_bytes, npix * 4)) != MI_OK) return rc;
+    }
+    mi_render_opts o = *opts;
+    o.want_signature = want_sig ? 1 : 0;
+    HIP_TRY(hipEventRecord(t0, c->stream));
+    rc = render_tiles(c, cam, &o, c->d_compact, want_sig ? c->d_sigc : nullptr, c->stream, stats);
+    if (rc != MI_OK) return rc;
+    HIP_TRY(launch_unpermute(c->d_compact, c->d_image, cam->screen_width, cam->screen_height, tx, 1, padded, c->stream));
+    if (out_rgb_f32) HIP_TRY(hipMemcpyAsync(out_rgb_f32, c->d_image, npix * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    if (out_rgb_u8) {
+        if ((rc = ensure((void**)&c->d_u8, &c->u8_bytes, npix * 3)) != MI_OK) return rc;
+        HIP_TRY(launch_tonemap(c->d_image, c->d_u8, (uint32_t)npix, 1.0f / cam->gamma, c->stream));
+        HIP_TRY(hipMemcpyAsync(out_rgb_u8, c->d_u8, npix * 3, hipMemcpyDeviceToHost, c->stream));
+    }
+    if (want_sig) {
+        HIP_TRY(launch_sig_unpermute(c->d_sigc, c->d_sigi, cam->screen_width, cam->screen_height, tx, 1, padded, c->stream));
+        HIP_TRY(hipMemcpyAsync(out_sig, c->d_sigi, npix * 4, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIP_TRY(hipEventRecord(t1, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (stats) {
+        float ms = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&ms, c->ev_start, c->ev_stop)); stats->kernel_ms = ms;
+        HIP_TRY(hipEventElapsedTime(&ms, t0, t1)); stats->total_ms = ms;
+    }
+    (void)hipEventDestroy(t0); (void)hipEventDestroy(t1);
+    return MI_OK;
+}

@@ -1,0 +1,147 @@
+// pt_device.h — device-resident scene layout shared by the host scene compiler
+// (mi_rt.cpp) and the HIP kernels (pt_kernels.hip).  gfx950 only.
+//
+// Layout rules (DESIGN.md "Data layout in HBM"):
+//  * The linear object list of Scene.objects (tracing.rs:215,330) is an array of
+//    fixed 64-byte records read at a wave-uniform index, so every lane of a wave
+//    reads the same record and the compiler serves it with scalar (SMEM) loads.
+//  * Each mesh BVH (reference topology, geometry.rs:190-217) is stored THREADED in
+//    DFS pre-order: node i's left child is i+1 and `skip` is the node that follows i's
+//    subtree.  The reference always descends left-then-right (geometry.rs:105-115),
+//    so a skip link replaces the traversal stack exactly.
+//  * Nodes are 2 x float4 (32 B), triangles 3 x float4 (a, e1, e2 — 48 B) so a lane
+//    fetches a node / triangle with 16-byte loads from LDS or L1/L2.
+//  * Per-triangle shading attributes (normals, uvs, tangent) are a separate array
+//    touched once per mesh HIT, not per candidate.
+#pragma once
+#include <stdint.h>
+
+namespace pt {
+
+constexpr int kTile = 32;            // MI_TILE
+constexpr int kTilePixels = kTile * kTile;
+constexpr int kBlock = 256;          // threads per workgroup = 4 waves of 64
+constexpr int kBlocksPerTile = kTilePixels / kBlock;
+
+enum : int { OBJ_SPHERE = 0, OBJ_TRIANGLE = 1, OBJ_PLANE = 2, OBJ_VOLUME = 3, OBJ_MESH = 4 };
+enum : int { MAT_LAMBERTIAN = 0, MAT_METAL = 1, MAT_DIELECTRIC = 2, MAT_PARAMETERIZED = 3, MAT_ISOTROPIC = 4 };
+
+// One entry of Scene.objects, 16 words.  Word use by kind:
+//   SPHERE   f[0..2] center, f[3] radius, f[4] radius*radius
+//   TRIANGLE f[0..2] a, f[3..5] e1=b-a, f[6..8] e2=c-a, f[9..11] normalize(e1 x e2)
+//   PLANE    f[0..2] point, f[3..5] normal
+//   VOLUME   f[0..2] boundary center, f[3] radius, f[4] radius*radius, f[5] -1/density
+//   MESH     ref = mesh index
+// Every derived value is computed on the host with the same f32 operation the
+// reference performs per ray (geometry.rs:400,434-435,449,517), so hoisting it is exact.
+struct alignas(16) DObject {
+    int32_t kind;
+    int32_t material;    // material index (phase function for VOLUME); unused for MESH
+    int32_t ref;         // mesh index for MESH
+    int32_t pad;
+    float   f[12];
+};
+static_assert(sizeof(DObject) == 64, "DObject must be 64 bytes");
+
+// Material, 16 words: kind, albedo, emission, roughness, metallic, ior, albedo/PI
+struct alignas(16) DMaterial {
+    int32_t kind;
+    float   albedo[3];
+    float   emission[3];
+    float   roughness;
+    float   metallic;
+    float   ior;
+    float   albedo_over_pi[3];   // materials.rs:41,128 `self.albedo / PI`, hoisted (exact: same f32 division)
+    float   pad[3];
+};
+static_assert(sizeof(DMaterial) == 64, "DMaterial must be 64 bytes");
+
+struct DTexture {
+    uint32_t offset;     // byte offset of the RGB8 texels in the texel pool
+    int32_t  width;
+    int32_t  height;
+    int32_t  pad;
+};
+
+// StaticMesh (geometry.rs:127-134)
+struct alignas(16) DMesh {
+    float    transform[16];      // column-major
+    float    inv_transform[16];  // column-major
+    int32_t  node_begin;         // index of the root node in the node pool
+    int32_t  node_end;           // one past the last node of this mesh
+    int32_t  tri_begin;          // first triangle in the triangle pools
+    int32_t  n_tris;
+    int32_t  material;           // -1 = ParameterizedMaterial from textures
+    int32_t  tex[5];             // -1 = None
+    int32_t  object_index;       // position in Scene.objects (tie-breaking)
+    int32_t  pad;
+};
+static_assert(sizeof(DMesh) % 16 == 0, "DMesh must be 16-byte sized");
+
+// per-triangle shading attributes, 20 floats = 5 float4
+struct alignas(16) DTriAttr {
+    float na[3], nb[3], nc[3];   // corner normals          geometry.rs:350
+    float ta[2], tb[2], tc[2];   // corner uvs              geometry.rs:355
+    float tan[3];                // StaticMesh::get_tangent geometry.rs:245-250, hoisted (exact)
+    float pad[2];
+};
+static_assert(sizeof(DTriAttr) == 80, "DTriAttr must be 80 bytes");
+
+struct DScene {
+    const DObject*   objects;
+    const DMaterial* materials;
+    const DMesh*     meshes;
+    const float*     nodes;      // float4 pairs: {bmin.xyz, skip(int)} {bmax.xyz, tri(int, -1 = interior)}
+    const float*     tris;       // float4 triples: {a.xyz, 0} {e1.xyz, 0} {e2.xyz, 0}
+    const DTriAttr*  triattr;
+    const DTexture*  textures;
+    const uint8_t*   texels;
+    int32_t n_objects;
+    int32_t n_meshes;
+    int32_t n_nodes;
+    int32_t n_tris;
+};
+
+// Camera::generate_rays constants (tracing.rs:160-163,187-191), computed once on the
+// host with the reference's f32 operations.
+struct DCamera {
+    float eye[3];
+    float rot[9];          // Matrix3::from_cols(normalize(view x up), up, -view), column-major
+    float pixel_size;      // 1 / H
+    float n;               // aa_sample_count as f32
+    float rootn;           // sqrt(n)
+    float half_rootn;      // 0.5 * rootn
+    float half_n;          // 0.5 * n
+    float cx_base;         // -0.5*W   (x as f32 + cx_base + 0.5)
+    float cy_base;         // 0.5 + 0.5*H
+    float focal_length;
+    float focus_dist;
+    float lens_radius;
+    float max_trace_dist;
+    uint32_t rootn_u;      // rootn as u32
+    uint32_t spp;          // aa_sample_count
+    uint32_t zone;         // rand UniformInt rejection zone for range = spp
+    uint32_t path_depth;
+    uint32_t width, height;
+};
+
+struct DRender {
+    uint32_t seed;
+    int32_t  rank, world;
+    uint32_t tiles_x, tiles_y, tiles_total;
+    uint32_t my_tiles;       // tiles owned by this rank
+    uint32_t lds_nodes;      // number of BVH nodes staged into LDS (0 = read from global)
+    uint32_t lds_tris;       // number of triangles staged into LDS
+};
+
+// kernel argument block of K1 (passed by value: lives in the kernarg segment / SGPRs)
+struct K1Args {
+    DScene  S;
+    DCamera C;
+    DRender R;
+    uint32_t seed_key;   // lowbias32(seed ^ 0x68e31da4)
+    float*    out;       // [tiles_padded][1024][3]
+    uint32_t* sig;       // [tiles_padded][1024] or nullptr
+};
+
+}  // namespace pt

@@ -1,0 +1,826 @@
+// pt_kernels.hip — hand-written HIP kernels for gfx950 (MI355X, CDNA4) of the
+// path-tracing hot path of mbk6/CS397RayTracingSP22.  No CUDA shims, no dual paths.
+//
+//   K1  pt_megakernel   Camera::generate_rays (tracing.rs:159-209) + Scene::shade_ray
+//                       (:300-324, made iterative) + the scene hit loop (:326-346) + every
+//                       intersect_ray (geometry.rs) + every scatter (materials.rs) +
+//                       Texture::sample (texture.rs:26-32) + the per-pixel mean (:232-241)
+//   K3  fb_unpermute    tile-major gathered buffers -> row-major W*H*3 f32
+//   K4  fb_tonemap_u8   tracing.rs:244-256 (saturate toward white, gamma, quantise)
+//
+// Execution model of K1 (DESIGN.md "K1"):
+//   * one lane = one pixel; a wave = an 8x8 pixel block; a 256-thread workgroup = a
+//     32x8 strip of one 32x32 image tile.
+//   * lane-persistent regeneration: a lane loops over its pixel's samples; the loop trip
+//     is ONE PATH SEGMENT, and a lane whose path ended starts its next sample in the same
+//     trip, so a wave never idles on short paths (64-wide waves make path-length
+//     divergence the first-order loss otherwise).
+//   * the object list is walked at a wave-uniform index: every lane reads the same
+//     64-byte record -> scalar loads, zero divergence in the list loop.
+//   * mesh BVHs are traversed STACKLESS through skip links (the reference's fixed
+//     left-then-right order, geometry.rs:105-115, makes this exact), nodes and triangles
+//     staged into LDS when they fit (teapot: 479 nodes + 240 triangles = 26.8 KB).
+//   * PARKED variant: phases are voted with __ballot/__popcll — lanes whose ray enters a
+//     mesh root box park, the rest keep tracing; the wave runs the traversal loop only
+//     when enough lanes are parked, so the long, divergent BVH loop runs at high lane
+//     utilisation.
+//
+// Numerics: every expression is written in the reference's evaluation order; the file
+// is compiled with -ffp-contract=off (Rust never fuses a*b+c) and HIP's default
+// correctly rounded f32 divide/sqrt, so each path makes bit-identical decisions to the
+// CPU restatement (tests compare per-pixel path signatures bit for bit).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "pt_device.h"
+
+#pragma clang fp contract(off)
+
+namespace pt {
+
+// ---------------------------------------------------------------- small vector math
+struct f3 { float x, y, z; };
+__device__ __forceinline__ f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ f3 ld3(const float* p) { return mk3(p[0], p[1], p[2]); }
+__device__ __forceinline__ f3 operator+(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ f3 operator-(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ f3 operator-(f3 a) { return mk3(-a.x, -a.y, -a.z); }
+__device__ __forceinline__ f3 operator*(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
+// InnerSpace::dot = (x + y) + z
+__device__ __forceinline__ float dot(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+__device__ __forceinline__ f3 cross(f3 a, f3 b) {
+    return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+__device__ __forceinline__ float mag2(f3 a) { return dot(a, a); }
+// InnerSpace::normalize = self * (1 / magnitude)
+__device__ __forceinline__ f3 normalize(f3 a) { return a * (1.0f / sqrtf(mag2(a))); }
+// Matrix3 * Vector3, column-major m[9]
+__device__ __forceinline__ f3 m3mul(const float* m, f3 v) {
+    return mk3((m[0] * v.x + m[3] * v.y) + m[6] * v.z,
+               (m[1] * v.x + m[4] * v.y) + m[7] * v.z,
+               (m[2] * v.x + m[5] * v.y) + m[8] * v.z);
+}
+__device__ __forceinline__ float clampf(float v, float lo, float hi) {
+    if (v < lo) v = lo;
+    if (v > hi) v = hi;
+    return v;
+}
+
+// ---------------------------------------------------------------- RNG (DESIGN.md "RNG")
+struct Rng { uint32_t s0, s1; };
+__device__ __forceinline__ uint32_t lowbias32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352du;
+    x ^= x >> 15; x *= 0x846ca68bu;
+    x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ uint32_t rotl32(uint32_t x, int k) { return (x << k) | (x >> (32 - k)); }
+__device__ __forceinline__ void rng_init(Rng& r, uint32_t seed_key, uint32_t pixel, uint32_t sample) {
+    // seed_key = lowbias32(seed ^ 0x68e31da4), hoisted to the host
+    uint32_t p0 = lowbias32(pixel + seed_key);
+    uint32_t p1 = lowbias32(p0 ^ 0xb5297a4du);
+    uint32_t s0 = lowbias32(p0 + sample * 0x9e3779b9u);
+    uint32_t s1 = lowbias32(p1 ^ (sample * 0x85ebca6bu));
+    if ((s0 | s1) == 0u) s1 = 1u;
+    r.s0 = s0; r.s1 = s1;
+}
+// xoroshiro64**
+__device__ __forceinline__ uint32_t next_u32(Rng& r) {
+    uint32_t s0 = r.s0, s1 = r.s1;
+    uint32_t result = rotl32(s0 * 0x9e3779bbu, 5) * 5u;
+    s1 ^= s0;
+    r.s0 = rotl32(s0, 26) ^ s1 ^ (s1 << 9);
+    r.s1 = rotl32(s1, 13);
+    return result;
+}
+__device__ __forceinline__ float value1_2(uint32_t bits) { return __uint_as_float(0x3f800000u | (bits >> 9)); }
+// rand 0.8.4 gen_range(0.0..1.0): value1_2*1 + (0-1)      (exact)
+__device__ __forceinline__ float gen01(Rng& r) { return value1_2(next_u32(r)) * 1.0f + (0.0f - 1.0f); }
+// rand 0.8.4 gen_range(-1.0..1.0): value1_2*2 + (-1-2)    (exact)
+__device__ __forceinline__ float genm11(Rng& r) { return value1_2(next_u32(r)) * 2.0f + (-1.0f - 2.0f); }
+// rand 0.8.4 gen_range(0..n): widening multiply + rejection zone
+__device__ __forceinline__ uint32_t gen_u32_below(Rng& r, uint32_t range, uint32_t zone) {
+    for (;;) {
+        uint32_t v = next_u32(r);
+        uint32_t hi = __umulhi(v, range), lo = v * range;
+        if (lo <= zone) return hi;
+    }
+}
+// tracing.rs:71-79
+__device__ __forceinline__ f3 rand_sphere_vec(Rng& r) {
+    for (;;) {
+        f3 d;
+        d.x = genm11(r); d.y = genm11(r); d.z = genm11(r);
+        if (mag2(d) <= 1.0f) return d;
+    }
+}
+// tracing.rs:81-89
+__device__ __forceinline__ f3 rand_disk_vec(Rng& r) {
+    for (;;) {
+        f3 d;
+        d.x = genm11(r); d.y = genm11(r); d.z = 0.0f;
+        if (mag2(d) <= 1.0f) return d;
+    }
+}
+
+// f32::ln for the free-flight distance (geometry.rs:517).  One fixed sequence of f32
+// operations (Cephes-style, <= 2 ulp), the same sequence the CPU checker uses.
+__device__ __forceinline__ float pt_logf(float x) {
+    if (!(x > 0.0f)) return (x == 0.0f) ? -__builtin_inff() : __builtin_nanf("");
+    if (x == __builtin_inff()) return x;
+    uint32_t ix = __float_as_uint(x);
+    int e = 0;
+    if (ix < 0x00800000u) { x = x * 8388608.0f; ix = __float_as_uint(x); e = -23; }
+    e += (int)(ix >> 23) - 126;
+    ix = (ix & 0x007fffffu) | 0x3f000000u;
+    float m = __uint_as_float(ix);
+    if (m < 0.70710678f) { e = e - 1; m = m + m; }
+    float f = m - 1.0f;
+    float z = f * f;
+    float p = 7.0376836292e-2f;
+    p = p * f + -1.1514610310e-1f;
+    p = p * f + 1.1676998740e-1f;
+    p = p * f + -1.2420140846e-1f;
+    p = p * f + 1.4249322787e-1f;
+    p = p * f + -1.6668057665e-1f;
+    p = p * f + 2.0000714765e-1f;
+    p = p * f + -2.4999993993e-1f;
+    p = p * f + 3.3333331174e-1f;
+    float y = (f * z) * p;
+    float fe = (float)e;
+    y = y + fe * -2.12194440e-4f;
+    y = y - 0.5f * z;
+    float r = f + y;
+    r = r + fe * 0.693359375f;
+    return r;
+}
+
+// ---------------------------------------------------------------- helpers tracing.rs:54-69
+__device__ __forceinline__ f3 reflect(f3 v, f3 n) { return v - n * (2.0f * dot(v, n)); }
+__device__ __forceinline__ float powi2(float a) { return a * a; }
+__device__ __forceinline__ float powi5(float a) { float a2 = a * a; float a4 = a2 * a2; return a * a4; }
+__device__ __forceinline__ float fresnel(f3 v, f3 n, float ir) {
+    float r0 = powi2((ir - 1.0f) / (ir + 1.0f));
+    return r0 + (1.0f - r0) * powi5(1.0f - fabsf(dot(v, n)));
+}
+__device__ __forceinline__ f3 refract(f3 v, f3 n, float eta) {
+    float cos_theta = fminf(dot(-v, n), 1.0f);
+    f3 r_out_perp = (v + n * cos_theta) * eta;
+    f3 r_out_parallel = n * (-sqrtf(fabsf(1.0f - mag2(r_out_perp))));
+    return r_out_perp + r_out_parallel;
+}
+
+// approx::ulps_eq!(a, b), f32 defaults (epsilon = f32::EPSILON, max_ulps = 4)
+__device__ __forceinline__ bool ulps_eq(float a, float b) {
+    if (fabsf(a - b) <= 1.1920929e-07f) return true;
+    if ((a < 0.0f) != (b < 0.0f)) return false;
+    int32_t ia = (int32_t)__float_as_uint(a), ib = (int32_t)__float_as_uint(b);
+    int32_t d = ia - ib;
+    if (d < 0) d = -d;
+    return d <= 4;
+}
+
+// sample_hemisphere's rotation (materials.rs:176-177):
+//   Basis3::between_vectors(unit_y, n).rotate_vector(dir)
+// cgmath's half-way quaternion with a = (0,1,0): a.b = n.y, a x b = (n.z, 0, -n.x),
+// |a|^2 = 1.  The zero y component of the quaternion is folded (x*0, x+0: exact).
+__device__ __forceinline__ f3 rotate_from_unit_y(f3 n, f3 dir) {
+    float k_cos_theta = n.y;
+    if (ulps_eq(k_cos_theta, 1.0f)) return dir;                       // identity quaternion
+    float k = sqrtf(1.0f * mag2(n));
+    float qs, qx, qz;
+    if (ulps_eq(k_cos_theta / k, -1.0f)) {
+        // pi rotation about normalize(unit_y x unit_x) = (0,0,-1): q = (0; 0,0,-1)
+        qs = 0.0f; qx = 0.0f; qz = -1.0f;
+    } else {
+        float s = k + k_cos_theta;
+        float cx = n.z, cz = -n.x;
+        float mag = sqrtf(s * s + ((cx * cx + 0.0f) + cz * cz));
+        float inv = 1.0f / mag;
+        qs = s * inv; qx = cx * inv; qz = cz * inv;
+    }
+    float x2 = qx + qx, z2 = qz + qz;
+    float xx2 = x2 * qx, xz2 = x2 * qz, zz2 = z2 * qz;
+    float sz2 = z2 * qs, sx2 = x2 * qs;
+    // columns of Matrix3::from(quaternion) with q.y = 0
+    float c0x = 1.0f - zz2, c0y = sz2,                  c0z = xz2;
+    float c1x = -sz2,       c1y = (1.0f - xx2) - zz2,   c1z = sx2;
+    float c2x = xz2,        c2y = -sx2,                 c2z = 1.0f - xx2;
+    return mk3((c0x * dir.x + c1x * dir.y) + c2x * dir.z,
+               (c0y * dir.x + c1y * dir.y) + c2y * dir.z,
+               (c0z * dir.x + c1z * dir.y) + c2z * dir.z);
+}
+
+// ---------------------------------------------------------------- primitive tests
+// Sphere::intersect_ray geometry.rs:395-413 -> parametric t, or miss
+__device__ __forceinline__ bool sphere_t(f3 o, f3 d, f3 center, float r2, float t_min, float t_max, float& t_out) {
+    f3 f = o - center;
+    float a = mag2(d);
+    float b = 2.0f * dot(f, d);
+    float c = mag2(f) - r2;
+    float disc = b * b - 4.0f * a * c;
+    if (disc < 0.0f) return false;
+    float sq = sqrtf(disc);
+    float t1 = (-b - sq) / (2.0f * a);
+    float t2 = (-b + sq) / (2.0f * a);
+    float t = (t1 >= t_min) ? t1 : t2;
+    if (t < t_min || t > t_max) return false;
+    t_out = t;
+    return true;
+}
+
+// Triangle / IndexedTriangle Moller-Trumbore geometry.rs:331-349, 431-447
+__device__ __forceinline__ bool tri_t(f3 o, f3 d, f3 a, f3 e1, f3 e2, float t_min, float t_max,
+                                      float& t_out, float& u_out, float& v_out) {
+    f3 q = cross(d, e2);
+    float g = dot(e1, q);
+    if (fabsf(g) < 0.0001f) return false;
+    float f = 1.0f / g;
+    f3 s = o - a;
+    float u = f * dot(s, q);
+    if (u < 0.0f) return false;
+    f3 r = cross(s, e1);
+    float v = f * dot(d, r);
+    if (v < 0.0f || u + v > 1.0f) return false;
+    float t = f * dot(e2, r);
+    if (t < t_min || t > t_max) return false;
+    t_out = t; u_out = u; v_out = v;
+    return true;
+}
+
+// AABB::intersect_ray geometry.rs:52-79 with 1/d hoisted out of the node loop (the
+// reference recomputes the same 1/d at every box).
+__device__ __forceinline__ bool slab(f3 bmin, f3 bmax, f3 o, f3 inv_d, float t_min, float t_max) {
+    float tmin = t_min, tmax = t_max;
+    {
+        float t0 = (bmin.x - o.x) * inv_d.x, t1 = (bmax.x - o.x) * inv_d.x;
+        if (inv_d.x < 0.0f) { float t = t0; t0 = t1; t1 = t; }
+        tmin = fmaxf(t0, tmin); tmax = fminf(t1, tmax);
+        if (tmax <= tmin) return false;
+    }
+    {
+        float t0 = (bmin.y - o.y) * inv_d.y, t1 = (bmax.y - o.y) * inv_d.y;
+        if (inv_d.y < 0.0f) { float t = t0; t0 = t1; t1 = t; }
+        tmin = fmaxf(t0, tmin); tmax = fminf(t1, tmax);
+        if (tmax <= tmin) return false;
+    }
+    {
+        float t0 = (bmin.z - o.z) * inv_d.z, t1 = (bmax.z - o.z) * inv_d.z;
+        if (inv_d.z < 0.0f) { float t = t0; t0 = t1; t1 = t; }
+        tmin = fmaxf(t0, tmin); tmax = fminf(t1, tmax);
+        if (tmax <= tmin) return false;
+    }
+    return true;
+}
+
+// Matrix4 (column-major) transforms, cgmath Transform3 (geometry.rs:304,307,297)
+__device__ __forceinline__ f3 xform_point(const float* m, f3 p) {
+    float x = ((m[0] * p.x + m[4] * p.y) + m[8]  * p.z) + m[12] * 1.0f;
+    float y = ((m[1] * p.x + m[5] * p.y) + m[9]  * p.z) + m[13] * 1.0f;
+    float z = ((m[2] * p.x + m[6] * p.y) + m[10] * p.z) + m[14] * 1.0f;
+    float w = ((m[3] * p.x + m[7] * p.y) + m[11] * p.z) + m[15] * 1.0f;
+    float iw = 1.0f / w;
+    return mk3(x * iw, y * iw, z * iw);
+}
+__device__ __forceinline__ f3 xform_vector(const float* m, f3 v) {
+    return mk3(((m[0] * v.x + m[4] * v.y) + m[8]  * v.z) + m[12] * 0.0f,
+               ((m[1] * v.x + m[5] * v.y) + m[9]  * v.z) + m[13] * 0.0f,
+               ((m[2] * v.x + m[6] * v.y) + m[10] * v.z) + m[14] * 0.0f);
+}
+__device__ __forceinline__ f3 xform_vector_transposed(const float* m, f3 v) {
+    return mk3(((m[0] * v.x + m[1] * v.y) + m[2]  * v.z) + m[3]  * 0.0f,
+               ((m[4] * v.x + m[5] * v.y) + m[6]  * v.z) + m[7]  * 0.0f,
+               ((m[8] * v.x + m[9] * v.y) + m[10] * v.z) + m[11] * 0.0f);
+}
+
+// Texture::sample texture.rs:26-32
+__device__ __forceinline__ f3 tex_sample(const DScene& S, int tex, float u, float v) {
+    DTexture t = S.textures[tex];
+    uint32_t W = (uint32_t)t.width, H = (uint32_t)t.height;
+    uint32_t x = (uint32_t)(clampf(u, 0.0f, 0.999f) * (float)W);
+    if (x > W - 1u) x = W - 1u;
+    uint32_t y = (uint32_t)((1.0f - clampf(v, 0.0f, 0.999f)) * (float)H);
+    if (y > H - 1u) y = H - 1u;
+    const uint8_t* px = S.texels + t.offset + ((size_t)y * W + x) * 3;
+    return mk3((float)px[0] / 255.0f, (float)px[1] / 255.0f, (float)px[2] / 255.0f);
+}
+
+// ---------------------------------------------------------------- BVH storage access
+template <bool LDS>
+struct Bvh {
+    const float4* nodes;      // global or LDS
+    const float4* tris;
+    __device__ __forceinline__ void node(int i, float4& n0, float4& n1) const { n0 = nodes[2 * i]; n1 = nodes[2 * i + 1]; }
+    __device__ __forceinline__ void tri(int i, f3& a, f3& e1, f3& e2) const {
+        float4 t0 = tris[3 * i], t1 = tris[3 * i + 1], t2 = tris[3 * i + 2];
+        a = mk3(t0.x, t0.y, t0.z); e1 = mk3(t1.x, t1.y, t1.z); e2 = mk3(t2.x, t2.y, t2.z);
+    }
+};
+
+// BVHNode::intersect_ray (geometry.rs:94-119) as a stackless threaded walk.
+// The recursion passes t_max down unchanged to the left child and the left subtree's
+// hit distance to the right child; unrolled over the whole tree that is ONE running
+// bound `best_t`, lowered by every accepted leaf hit in DFS order, with `t <= best_t`
+// accepted (geometry.rs:349 rejects only t > t_max), so a later equal hit replaces an
+// earlier one exactly as `best_hit = hit_opt` (:114) does.
+// "while-while" shape: advance every lane through interior nodes until it reaches a
+// leaf (or the end), then run the triangle test for the lanes that hold a leaf.
+template <class BVH>
+__device__ __forceinline__ void traverse_mesh(const BVH& B, int node_begin, int node_end, int tri_begin,
+                                              f3 o, f3 d, float t_min, float t_max,
+                                              float& best_t, int& best_tri, float& best_u, float& best_v) {
+    f3 inv_d = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);       // geometry.rs:57
+    best_t = t_max; best_tri = -1; best_u = 0.0f; best_v = 0.0f;
+    int i = node_begin;
+    while (i < node_end) {
+        int leaf_tri = -1;
+        while (i < node_end) {
+            float4 n0, n1;
+            B.node(i, n0, n1);
+            int tri = __float_as_int(n1.w);
+            if (tri >= 0) { leaf_tri = tri; break; }                       // geometry.rs:95
+            bool hit = slab(mk3(n0.x, n0.y, n0.z), mk3(n1.x, n1.y, n1.z), o, inv_d, t_min, best_t);   // :103
+            i = hit ? i + 1 : __float_as_int(n0.w);
+        }
+        if (leaf_tri >= 0) {
+            f3 a, e1, e2;
+            B.tri(tri_begin + leaf_tri, a, e1, e2);
+            float t, u, v;
+            if (tri_t(o, d, a, e1, e2, t_min, best_t, t, u, v)) {          // :97, :106/:113
+                best_t = t; best_tri = leaf_tri; best_u = u; best_v = v;
+            }
+            i = i + 1;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- path state
+struct Path {
+    f3 o, d;            // current ray
+    f3 T, L;            // throughput, radiance of this sample
+    Rng rng;
+    uint32_t depth;
+    uint32_t sig;
+};
+
+// closest hit so far over Scene.objects
+struct Best {
+    float t;            // distance of the best hit; valid when obj >= 0
+    int   obj;          // index into Scene.objects, -1 = none
+    int   tri;          // mesh triangle (mesh hits)
+    float u, v;         // barycentrics (mesh hits)
+};
+
+// Scene::intersect_ray's replacement rule (tracing.rs:333-336): strictly closer wins;
+// on equal distance the object that comes first in Scene.objects is kept.
+__device__ __forceinline__ void consider(Best& b, float t, int obj, int tri, float u, float v) {
+    bool take = (b.obj < 0) || (t < b.t) || (t == b.t && obj < b.obj);
+    if (take) { b.t = t; b.obj = obj; b.tri = tri; b.u = u; b.v = v; }
+}
+
+// surface point handed to the scatter stage
+struct Surf {
+    f3 p, n;            // hitpoint (world), normal (ray-facing; zero inside a volume)
+    bool frontface;
+    int   kind;
+    f3 albedo, emission, brdf_diffuse;   // brdf_diffuse = albedo / PI
+    float roughness, metallic, ior;
+};
+
+__device__ __forceinline__ void load_material(const DScene& S, int id, Surf& s) {
+    const DMaterial* m = &S.materials[id];
+    s.kind = m->kind;
+    s.albedo = ld3(m->albedo); s.emission = ld3(m->emission);
+    s.brdf_diffuse = ld3(m->albedo_over_pi);
+    s.roughness = m->roughness; s.metallic = m->metallic; s.ior = m->ior;
+}
+
+// RayHit::new (tracing.rs:121-133): face the normal against the ray
+__device__ __forceinline__ void face(f3 normal, f3 dir, f3& n_out, bool& frontface) {
+    frontface = dot(normal, dir) < 0.0f;
+    n_out = frontface ? normal : -normal;
+}
+
+// Build the hit record of the winning object (the reference builds one per candidate
+// and keeps the closest; only the winner's is observable).
+__device__ __forceinline__ void resolve_hit(const DScene& S, const Best& b, f3 o, f3 d, Surf& s) {
+    const DObject* ob = &S.objects[b.obj];
+    int kind = ob->kind;
+    if (kind == OBJ_MESH) {
+        const DMesh* M = &S.meshes[ob->ref];
+        // geometry.rs:304 — object-space ray (direction NOT renormalised)
+        f3 oo = xform_point(M->inv_transform, o);
+        f3 od = xform_vector(M->inv_transform, d);
+        const DTriAttr* A = &S.triattr[M->tri_begin + b.tri];
+        float u = b.u, v = b.v, w = (1.0f - u - v);
+        // geometry.rs:351 normalize(u*nb + v*nc + (1-u-v)*na)
+        f3 mesh_normal = normalize((ld3(A->nb) * u + ld3(A->nc) * v) + ld3(A->na) * w);
+        f3 n; bool ff;
+        face(mesh_normal, od, n, ff);                                    // :352 RayHit::new in object space
+        f3 hp_obj = oo + od * b.t;                                       // tracing.rs:125
+        float tu = (u * A->tb[0] + v * A->tc[0]) + w * A->ta[0];         // :356
+        float tv = (u * A->tb[1] + v * A->tc[1]) + w * A->ta[1];
+        if (M->tex[4] >= 0) {                                            // geometry.rs:276-283
+            f3 tan_approx = ld3(A->tan);
+            f3 bitangent = normalize(cross(n, tan_approx));              // :360
+            f3 tangent = normalize(cross(bitangent, n));                 // :361
+            f3 smp = tex_sample(S, M->tex[4], tu, tv);
+            f3 nv = smp * 2.0f - mk3(1.0f, 1.0f, 1.0f);                  // :282
+            // Matrix3::from_cols(tangent, bitangent, normal) * nv            :283
+            n = (tangent * nv.x + bitangent * nv.y) + n * nv.z;
+        }
+        s.p = xform_point(M->transform, hp_obj);                         // :307
+        s.n = normalize(xform_vector_transposed(M->inv_transform, n));   // :297
+        s.frontface = ff;
+        if (M->material >= 0) {
+            load_material(S, M->material, s);                            // :255-256
+        } else {                                                         // :259-269
+            s.kind = MAT_PARAMETERIZED;
+            s.albedo   = (M->tex[0] >= 0) ? tex_sample(S, M->tex[0], tu, tv) : mk3(0.0f, 0.0f, 0.0f);
+            s.emission = (M->tex[1] >= 0) ? tex_sample(S, M->tex[1], tu, tv) : mk3(0.0f, 0.0f, 0.0f);
+            s.metallic  = (M->tex[2] >= 0) ? tex_sample(S, M->tex[2], tu, tv).x : 0.0f;
+            s.roughness = (M->tex[3] >= 0) ? tex_sample(S, M->tex[3], tu, tv).x : 1.0f;
+            const float PI = 3.14159265358979323846f;
+            s.brdf_diffuse = mk3(s.albedo.x / PI, s.albedo.y / PI, s.albedo.z / PI);   // materials.rs:128
+            s.ior = 0.0f;
+        }
+        return;
+    }
+    load_material(S, ob->material, s);
+    f3 hp = o + d * b.t;                                                 // tracing.rs:125
+    s.p = hp;
+    if (kind == OBJ_SPHERE) {
+        f3 c = ld3(ob->f);
+        face(normalize(hp - c), d, s.n, s.frontface);                    // geometry.rs:411
+    } else if (kind == OBJ_TRIANGLE) {
+        face(ld3(ob->f + 9), d, s.n, s.frontface);                       // geometry.rs:449
+    } else if (kind == OBJ_PLANE) {
+        // geometry.rs:476-478,487: n = signum(origin_dist) * normal
+        f3 normal = ld3(ob->f + 3);
+        float origin_dist = dot(o - ld3(ob->f), normal);
+        float sg = (origin_dist != origin_dist) ? origin_dist : (__float_as_uint(origin_dist) >> 31 ? -1.0f : 1.0f);
+        face(normal * sg, d, s.n, s.frontface);
+    } else {                                                             // OBJ_VOLUME geometry.rs:520
+        face(mk3(0.0f, 0.0f, 0.0f), d, s.n, s.frontface);
+    }
+}
+
+// One non-mesh object of Scene.objects against the ray (wave-uniform `ob`).
+__device__ __forceinline__ void test_object(const DObject* ob, int idx, f3 o, f3 d, float t_min, float t_max,
+                                            Rng& rng, Best& best) {
+    int kind = ob->kind;
+    if (kind == OBJ_TRIANGLE) {
+        float t, u, v;
+        if (tri_t(o, d, ld3(ob->f), ld3(ob->f + 3), ld3(ob->f + 6), t_min, t_max, t, u, v))
+            consider(best, t, idx, -1, 0.0f, 0.0f);
+    } else if (kind == OBJ_SPHERE) {
+        float t;
+        if (sphere_t(o, d, ld3(ob->f), ob->f[4], t_min, t_max, t)) consider(best, t, idx, -1, 0.0f, 0.0f);
+    } else if (kind == OBJ_PLANE) {                                       // geometry.rs:474-489
+        f3 normal = ld3(ob->f + 3);
+        float origin_dist = dot(o - ld3(ob->f), normal);
+        float sg = (origin_dist != origin_dist) ? origin_dist : (__float_as_uint(origin_dist) >> 31 ? -1.0f : 1.0f);
+        f3 n = normal * sg;
+        float dd = dot(d, n);
+        if (!(dd >= 0.0f)) {
+            float t = fabsf(origin_dist) / fabsf(dd);
+            if (!(t < t_min || t > t_max)) consider(best, t, idx, -1, 0.0f, 0.0f);
+        }
+    } else if (kind == OBJ_VOLUME) {                                      // geometry.rs:502-526
+        const float F32_MIN = -3.40282347e+38f, F32_MAX = 3.40282347e+38f;
+        f3 c = ld3(ob->f);
+        float r2 = ob->f[4];
+        float t_entr, t_exit;
+        if (sphere_t(o, d, c, r2, F32_MIN, F32_MAX, t_entr) &&
+            sphere_t(o, d, c, r2, t_entr + 0.0001f, F32_MAX, t_exit)) {
+            if (!(t_exit < t_min || t_entr > t_max)) {
+                float t_start = fmaxf(t_entr, t_min);
+                float t_end = fminf(t_exit, t_max);
+                float dist_in_volume = t_end - t_start;
+                float dist_before_scatter = ob->f[5] * pt_logf(gen01(rng));     // :517, f[5] = -1/density
+                if (dist_before_scatter < dist_in_volume)
+                    consider(best, t_start + dist_before_scatter, idx, -1, 0.0f, 0.0f);
+            }
+        }
+    }
+}
+
+// Material::scatter (materials.rs) for the resolved surface; returns the new direction
+// and the throughput factor dot_term*brdf/pdf of tracing.rs:313-316.
+__device__ __forceinline__ void scatter(const Surf& s, f3 d, Rng& rng, f3& new_d, f3& weight) {
+    int kind = s.kind;
+    bool diffuse = (kind == MAT_LAMBERTIAN);
+    f3 brdf;
+    float inv_pdf = 1.0f;
+    if (kind == MAT_PARAMETERIZED) {                                     // materials.rs:116-120
+        float fr = fresnel(d, s.n, 1.5f);
+        float k_s = fr * (1.0f - s.roughness);
+        float k_d = (1.0f - k_s) * (1.0f - s.metallic);
+        diffuse = gen01(rng) < k_d;
+    }
+    if (kind == MAT_DIELECTRIC) {                                        // materials.rs:80-90
+        float eta = s.frontface ? 1.0f / s.ior : s.ior;
+        float cosv = fminf(-dot(d, s.n), 1.0f);
+        bool critical_angle = eta * sqrtf(1.0f - powi2(cosv)) > 1.0f;
+        float fresnel_factor = fresnel(d, s.n, s.ior);
+        bool will_refract = !critical_angle && (gen01(rng) >= fresnel_factor);   // short-circuit draw
+        new_d = will_refract ? refract(d, s.n, eta) : reflect(d, s.n);
+        brdf = mk3(1.0f, 1.0f, 1.0f);
+    } else {
+        // every other material draws rand_sphere_vec next; one shared rejection loop
+        f3 v = rand_sphere_vec(rng);
+        if (diffuse) {                                                   // sample_hemisphere :171-178
+            v.y = fabsf(v.y);
+            new_d = rotate_from_unit_y(s.n, v);
+            brdf = s.brdf_diffuse;                                       // albedo / PI
+            inv_pdf = 6.28318530717958647692f;                           // pdf = 1/(2*PI)
+        } else if (kind == MAT_ISOTROPIC) {                              // :161
+            new_d = v;
+            brdf = s.albedo;
+        } else {                                                         // Metal :62 / Parameterized :137
+            new_d = reflect(d, s.n) + v * s.roughness;
+            if (kind == MAT_METAL) brdf = s.albedo;
+            else {                                                       // lerpvec(1, albedo, metallic) tracing.rs:95-97
+                float k = s.metallic;
+                brdf = mk3(1.0f, 1.0f, 1.0f) * (1.0f - k) + s.albedo * k;
+            }
+        }
+    }
+    // tracing.rs:313
+    float dot_term = (mag2(s.n) > 0.0f) ? clampf(fabsf(dot(new_d, s.n)), 0.0f, 1.0f) : 1.0f;
+    float wgt = dot_term * inv_pdf;
+    weight = mk3(brdf.x * wgt, brdf.y * wgt, brdf.z * wgt);
+}
+
+// Camera::generate_rays for one sample (tracing.rs:165-206)
+__device__ __forceinline__ void generate_ray(const DCamera& C, uint32_t px, uint32_t py, uint32_t i, Rng& rng, f3& o, f3& d) {
+    float rand_x = (float)gen_u32_below(rng, C.spp, C.zone);             // :167
+    float rand_y = (float)gen_u32_below(rng, C.spp, C.zone);             // :168
+    float subpixel_x = (float)(i / C.rootn_u);                           // :169
+    float subpixel_y = (float)(i % C.rootn_u);                           // :170
+    float off_x = (subpixel_x - C.half_rootn) * C.pixel_size / C.rootn + (rand_x - C.half_n) * C.pixel_size / C.n;
+    float off_y = (subpixel_y - C.half_rootn) * C.pixel_size / C.rootn + (rand_y - C.half_n) * C.pixel_size / C.n;
+    f3 center = mk3(C.pixel_size * ((float)px + C.cx_base + 0.5f) + off_x,          // :178
+                    C.pixel_size * (C.cy_base - (float)py) + off_y,                 // :179
+                    -C.focal_length);
+    f3 focus = normalize(center) * C.focus_dist;                         // :183
+    f3 lens = rand_disk_vec(rng) * C.lens_radius;                        // :184
+    o = ld3(C.eye) + m3mul(C.rot, lens);                                 // :197
+    d = m3mul(C.rot, normalize(focus - lens));                           // :201,204
+}
+
+// path-signature steps (diagnostic; DESIGN.md "Path signature")
+__device__ __forceinline__ uint32_t sig_hit(uint32_t sig, float t, int obj) {
+    return lowbias32((sig ^ __float_as_uint(t)) + (uint32_t)(obj + 1) * 0x9e3779b1u);
+}
+__device__ __forceinline__ uint32_t sig_end_miss(uint32_t sig, const Rng& r) {
+    return lowbias32(sig ^ r.s0 ^ rotl32(r.s1, 16));
+}
+__device__ __forceinline__ uint32_t sig_end_depth(uint32_t sig) { return lowbias32(sig ^ 0x5bd1e995u); }
+
+// ---------------------------------------------------------------- K1
+extern __shared__ float4 k1_lds[];
+
+template <bool LDS, bool PARK, bool SIG>
+__global__ __launch_bounds__(kBlock) void pt_megakernel(K1Args A) {
+    const DScene& S = A.S;
+    const DCamera& C = A.C;
+
+    // ---- stage the mesh BVH into LDS (nodes then triangles) ----
+    Bvh<LDS> B;
+    if (LDS) {
+        const float4* gn = reinterpret_cast<const float4*>(S.nodes);
+        const float4* gt = reinterpret_cast<const float4*>(S.tris);
+        int nn = (int)A.R.lds_nodes * 2, nt = (int)A.R.lds_tris * 3;
+        for (int k = threadIdx.x; k < nn; k += kBlock) k1_lds[k] = gn[k];
+        for (int k = threadIdx.x; k < nt; k += kBlock) k1_lds[nn + k] = gt[k];
+        __syncthreads();
+        B.nodes = k1_lds; B.tris = k1_lds + nn;
+    } else {
+        B.nodes = reinterpret_cast<const float4*>(S.nodes);
+        B.tris = reinterpret_cast<const float4*>(S.tris);
+    }
+
+    // ---- lane -> pixel ----
+    const uint32_t slot = blockIdx.x / kBlocksPerTile;            // tile slot of this rank
+    const uint32_t sub = blockIdx.x % kBlocksPerTile;             // 32x8 strip inside the tile
+    const uint32_t tile = slot * (uint32_t)A.R.world + (uint32_t)A.R.rank;
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t in_x = wave * 8 + (lane & 7), in_y = sub * 8 + (lane >> 3);
+    const uint32_t out_idx = slot * kTilePixels + in_y * kTile + in_x;
+    uint32_t px = 0, py = 0;
+    bool in_image = false;
+    if (tile < A.R.tiles_total) {
+        px = (tile % A.R.tiles_x) * kTile + in_x;
+        py = (tile / A.R.tiles_x) * kTile + in_y;
+        in_image = (px < C.width) && (py < C.height);
+    }
+    const uint32_t pixel = py * C.width + px;
+    const float t_min = 0.001f, t_max = C.max_trace_dist;         // tracing.rs:305
+
+    f3 accum = mk3(0.0f, 0.0f, 0.0f);                             // tracing.rs:232
+    uint32_t sigsum = 0;
+    uint32_t sample = 0;
+    const uint32_t spp = in_image ? C.spp : 0u;
+
+    Path P;
+    P.o = P.d = P.T = P.L = mk3(0.0f, 0.0f, 0.0f); P.depth = 0; P.sig = 0; P.rng.s0 = P.rng.s1 = 1u;
+    bool fresh = true;          // lane needs a new camera ray
+    bool alive = true;          // lane still has samples to do
+
+    // PARK state: the lane's ray entered >=1 mesh root box and waits for the traversal phase
+    bool parked = false;
+    Best best; best.t = 0.0f; best.obj = -1; best.tri = -1; best.u = best.v = 0.0f;
+
+    while (true) {
+        bool run_list = true, run_mesh = true;
+        if (PARK) {
+            // phase vote: trace the mesh phase only when most lanes wait for it
+            unsigned long long m_park = __ballot(alive && parked);
+            unsigned long long m_list = __ballot(alive && !parked);
+            int n_park = __popcll(m_park), n_list = __popcll(m_list);
+            if (n_park == 0 && n_list == 0) break;
+            run_mesh = (n_list == 0) || (n_park >= 40);
+            run_list = !run_mesh;
+        } else {
+            if (!__any(alive)) break;
+        }
+
+        bool resolved = false;   // this lane finished a segment's intersection this trip
+
+        if (run_list && alive && !parked) {
+            if (fresh) {
+                if (sample >= spp) { alive = false; }
+                else {
+                    rng_init(P.rng, A.seed_key, pixel, sample);
+                    generate_ray(C, px, py, sample, P.rng, P.o, P.d);
+                    P.T = mk3(1.0f, 1.0f, 1.0f); P.L = mk3(0.0f, 0.0f, 0.0f); P.depth = 0; P.sig = 0;
+                    fresh = false;
+                }
+            }
+            if (alive) {
+                // ---- Scene::intersect_ray over the non-mesh objects, wave-uniform index ----
+                best.obj = -1; best.t = 0.0f; best.tri = -1; best.u = best.v = 0.0f;
+                for (int k = 0; k < S.n_objects; k++) {
+                    const DObject* ob = &S.objects[k];
+                    if (ob->kind != OBJ_MESH) test_object(ob, k, P.o, P.d, t_min, t_max, P.rng, best);
+                }
+                if (S.n_meshes == 0) resolved = true;
+                else if (PARK) {
+                    // does the ray enter any mesh root box?  (geometry.rs:103 at the root)
+                    bool enters = false;
+                    for (int m = 0; m < S.n_meshes; m++) {
+                        const DMesh* M = &S.meshes[m];
+                        f3 oo = xform_point(M->inv_transform, P.o);
+                        f3 od = xform_vector(M->inv_transform, P.d);
+                        float4 n0, n1;
+                        B.node(M->node_begin, n0, n1);
+                        if (__float_as_int(n1.w) >= 0) enters = true;      // single-triangle mesh: root is a leaf
+                        else {
+                            f3 inv_d = mk3(1.0f / od.x, 1.0f / od.y, 1.0f / od.z);
+                            enters = enters || slab(mk3(n0.x, n0.y, n0.z), mk3(n1.x, n1.y, n1.z), oo, inv_d, t_min, t_max);
+                        }
+                    }
+                    if (enters) parked = true; else resolved = true;
+                }
+            }
+        }
+
+        if (run_mesh && alive && (PARK ? parked : (!resolved && S.n_meshes > 0))) {
+            // ---- StaticMesh::intersect_ray for every mesh (geometry.rs:301-314) ----
+            for (int m = 0; m < S.n_meshes; m++) {
+                const DMesh* M = &S.meshes[m];
+                f3 oo = xform_point(M->inv_transform, P.o);
+                f3 od = xform_vector(M->inv_transform, P.d);
+                float bt, bu, bv; int btri;
+                traverse_mesh(B, M->node_begin, M->node_end, M->tri_begin, oo, od, t_min, t_max, bt, btri, bu, bv);
+                if (btri >= 0) consider(best, bt, M->object_index, btri, bu, bv);
+            }
+            parked = false;
+            resolved = true;
+        }
+
+        if (resolved) {
+            // ---- Scene::shade_ray, one level (tracing.rs:305-321) ----
+            bool end_path;
+            if (best.obj < 0) {                                           // :306 background = 0
+                end_path = true;
+                if (SIG) P.sig = sig_end_miss(P.sig, P.rng);
+            } else {
+                if (SIG) P.sig = sig_hit(P.sig, best.t, best.obj);
+                Surf s;
+                resolve_hit(S, best, P.o, P.d, s);
+                // L += T * emission                                         :321
+                P.L = mk3(P.L.x + P.T.x * s.emission.x, P.L.y + P.T.y * s.emission.y, P.L.z + P.T.z * s.emission.z);
+                P.depth++;
+                if (P.depth >= C.path_depth) {                            // :301 at the next level
+                    end_path = true;
+                    if (SIG) P.sig = sig_end_depth(P.sig);
+                } else {
+                    f3 nd, w;
+                    scatter(s, P.d, P.rng, nd, w);                        // :312-316
+                    P.o = s.p; P.d = nd;
+                    P.T = mk3(P.T.x * w.x, P.T.y * w.y, P.T.z * w.z);
+                    end_path = false;
+                }
+            }
+            if (end_path) {
+                accum = accum + P.L;                                      // :238
+                if (SIG) sigsum += P.sig;
+                sample++;
+                fresh = true;
+            }
+        }
+    }
+
+    // ---- per-pixel mean (tracing.rs:241); pixels outside the image are written as 0 ----
+    float n = (float)C.spp;
+    float* o3 = A.out + (size_t)out_idx * 3;
+    if (in_image) { o3[0] = accum.x / n; o3[1] = accum.y / n; o3[2] = accum.z / n; }
+    else { o3[0] = 0.0f; o3[1] = 0.0f; o3[2] = 0.0f; }
+    if (SIG && A.sig) A.sig[out_idx] = in_image ? sigsum : 0u;
+}
+
+// ---------------------------------------------------------------- K3: un-permute
+// gathered[world][tiles_padded][1024][3] -> image[H][W][3].  One thread per pixel.
+__global__ __launch_bounds__(256) void fb_unpermute(const float* __restrict__ gathered, float* __restrict__ image,
+                                                    uint32_t width, uint32_t height, uint32_t tiles_x,
+                                                    uint32_t world, uint32_t tiles_padded) {
+    uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= width * height) return;
+    uint32_t x = idx % width, y = idx / width;
+    uint32_t tile = (y / kTile) * tiles_x + (x / kTile);
+    uint32_t rank = tile % world, slot = tile / world;
+    size_t src = (((size_t)rank * tiles_padded + slot) * kTilePixels + (y % kTile) * kTile + (x % kTile)) * 3;
+    size_t dst = (size_t)idx * 3;
+    image[dst] = gathered[src]; image[dst + 1] = gathered[src + 1]; image[dst + 2] = gathered[src + 2];
+}
+
+// same mapping for the u32 signature plane
+__global__ __launch_bounds__(256) void sig_unpermute(const uint32_t* __restrict__ gathered, uint32_t* __restrict__ image,
+                                                     uint32_t width, uint32_t height, uint32_t tiles_x,
+                                                     uint32_t world, uint32_t tiles_padded) {
+    uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= width * height) return;
+    uint32_t x = idx % width, y = idx / width;
+    uint32_t tile = (y / kTile) * tiles_x + (x / kTile);
+    uint32_t rank = tile % world, slot = tile / world;
+    image[idx] = gathered[((size_t)rank * tiles_padded + slot) * kTilePixels + (y % kTile) * kTile + (x % kTile)];
+}
+
+// ---------------------------------------------------------------- K4: tone-map
+// tracing.rs:244-256: saturate toward white, clamp, pow(1/gamma), *255.9999, `as u8`
+__global__ __launch_bounds__(256) void fb_tonemap_u8(const float* __restrict__ image, uint8_t* __restrict__ out,
+                                                     uint32_t n_pixels, float inv_gamma) {
+    uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_pixels) return;
+    float tmp[3] = { image[3 * idx], image[3 * idx + 1], image[3 * idx + 2] };
+    float fc[3] = { tmp[0], tmp[1], tmp[2] };
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        float d = tmp[i] - 1.0f;
+        if (d > 0.0f) { fc[(i + 1) % 3] += d; fc[(i + 2) % 3] += d; }
+    }
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        float q = powf(clampf(fc[i], 0.0f, 1.0f), inv_gamma) * 255.9999f;
+        uint8_t b = (q != q) ? 0 : (q <= 0.0f ? 0 : (q >= 255.0f ? 255 : (uint8_t)q));
+        out[3 * idx + i] = b;
+    }
+}
+
+// ---------------------------------------------------------------- launch wrappers
+hipError_t launch_megakernel(const K1Args& args, uint32_t n_blocks, bool lds, bool park, bool sig,
+                             size_t lds_bytes, hipStream_t stream) {
+    dim3 grid(n_blocks), block(kBlock);
+#define PT_LAUNCH(L, P, G) hipLaunchKernelGGL((pt_megakernel<L, P, G>), grid, block, (L) ? lds_bytes : 0, stream, args)
+    if (lds) {
+        if (park) { if (sig) PT_LAUNCH(true, true, true); else PT_LAUNCH(true, true, false); }
+        else      { if (sig) PT_LAUNCH(true, false, true); else PT_LAUNCH(true, false, false); }
+    } else {
+        if (park) { if (sig) PT_LAUNCH(false, true, true); else PT_LAUNCH(false, true, false); }
+        else      { if (sig) PT_LAUNCH(false, false, true); else PT_LAUNCH(false, false, false); }
+    }
+#undef PT_LAUNCH
+    return hipGetLastError();
+}
+
+hipError_t launch_unpermute(const float* gathered, float* image, uint32_t width, uint32_t height, uint32_t tiles_x,
+                            uint32_t world, uint32_t tiles_padded, hipStream_t stream) {
+    uint32_t n = width * height;
+    hipLaunchKernelGGL(fb_unpermute, dim3((n + 255) / 256), dim3(256), 0, stream, gathered, image, width, height,
+                       tiles_x, world, tiles_padded);
+    return hipGetLastError();
+}
+hipError_t launch_sig_unpermute(const uint32_t* gathered, uint32_t* image, uint32_t width, uint32_t height,
+                                uint32_t tiles_x, uint32_t world, uint32_t tiles_padded, hipStream_t stream) {
+    uint32_t n = width * height;
+    hipLaunchKernelGGL(sig_unpermute, dim3((n + 255) / 256), dim3(256), 0, stream, gathered, image, width, height,
+                       tiles_x, world, tiles_padded);
+    return hipGetLastError();
+}
+hipError_t launch_tonemap(const float* image, uint8_t* out, uint32_t n_pixels, float inv_gamma, hipStream_t stream) {
+    hipLaunchKernelGGL(fb_tonemap_u8, dim3((n_pixels + 255) / 256), dim3(256), 0, stream, image, out, n_pixels, inv_gamma);
+    return hipGetLastError();
+}
+
+}  // namespace pt

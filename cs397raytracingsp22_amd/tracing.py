@@ -1,0 +1,158 @@
+"""Host-side mirror of src/util/tracing.rs: `Camera` and `Scene` with the reference's
+field names; `Scene.render_to_image()` keeps its meaning (tracing.rs:221-263) and
+becomes flatten -> one call through the C ABI (include/mi_rt.h) -> image bytes.
+
+Everything below `render_to_image` — generate_rays, shade_ray, the hit loop, every
+intersect_ray / scatter / texture sample — runs in the HIP kernels of csrc/.  There is
+no CPU implementation of the path in this package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import List, Optional
+import numpy as np
+
+from . import abi
+from .geometry import FlatBuilder, FlatScene, Intersectable
+
+
+class CameraProjectionMode:          # tracing.rs:27-30
+    Orthographic = abi.MI_PROJ_ORTHOGRAPHIC
+    Perspective = abi.MI_PROJ_PERSPECTIVE
+
+
+class ShadingMode:                   # tracing.rs:32-35
+    Phong = abi.MI_SHADE_PHONG
+    PathTrace = abi.MI_SHADE_PATHTRACE
+
+
+@dataclass
+class Camera:                        # tracing.rs:138-155, same fields
+    eyepoint: tuple = (0.0, 2.0, 5.5)
+    view_dir: tuple = (0.0, 0.0, -1.0)
+    up: tuple = (0.0, 1.0, 0.0)
+    projection_mode: int = CameraProjectionMode.Perspective
+    shading_mode: int = ShadingMode.PathTrace
+    path_depth: int = 10
+    path_samples: int = 1
+    screen_width: int = 100
+    screen_height: int = 100
+    focal_length: float = 0.6
+    focus_dist: float = 5.0
+    lens_radius: float = 0.0
+    aa_sample_count: int = 100
+    max_trace_dist: float = 100.0
+    gamma: float = 2.0
+
+    def to_pod(self) -> abi.mi_camera_desc:
+        c = abi.mi_camera_desc()
+        c.eyepoint = abi.f3(*np.asarray(self.eyepoint, np.float32))
+        c.view_dir = abi.f3(*np.asarray(self.view_dir, np.float32))
+        c.up = abi.f3(*np.asarray(self.up, np.float32))
+        c.projection_mode, c.shading_mode = self.projection_mode, self.shading_mode
+        c.path_depth, c.path_samples = self.path_depth, self.path_samples
+        c.screen_width, c.screen_height = self.screen_width, self.screen_height
+        c.focal_length, c.focus_dist, c.lens_radius = self.focal_length, self.focus_dist, self.lens_radius
+        c.aa_sample_count = self.aa_sample_count
+        c.max_trace_dist, c.gamma = self.max_trace_dist, self.gamma
+        return c
+
+
+class Context:
+    """One mi_ctx = one GPU (one process per GPU: pass LOCAL_RANK)."""
+
+    def __init__(self, device: int = 0):
+        self._lib = abi.load()
+        self._h = C.c_void_p()
+        abi.check(self._lib.mi_ctx_create(device, C.byref(self._h)))
+        self.device = device
+
+    def close(self):
+        if self._h:
+            self._lib.mi_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload(self, flat: FlatScene):
+        abi.check(self._lib.mi_scene_upload(self._h, C.byref(flat.desc)))
+
+    def render(self, cam: Camera, seed: int = 1, want_f32=True, want_u8=True, want_sig=False,
+               variant: int = abi.MI_VARIANT_DEFAULT):
+        """mi_render: whole image on this GPU.  Returns (f32 [H,W,3] | None, u8 [H,W,3] | None,
+        sig [H,W] | None, mi_stats)."""
+        pod = cam.to_pod()
+        opts = abi.mi_render_opts(seed=seed, rank=0, world=1, variant=variant, want_signature=int(want_sig))
+        H, W = cam.screen_height, cam.screen_width
+        f32 = np.empty((H, W, 3), np.float32) if want_f32 else None
+        u8 = np.empty((H, W, 3), np.uint8) if want_u8 else None
+        sig = np.empty((H, W), np.uint32) if want_sig else None
+        st = abi.mi_stats()
+        abi.check(self._lib.mi_render(
+            self._h, C.byref(pod), C.byref(opts),
+            f32.ctypes.data if f32 is not None else None,
+            u8.ctypes.data if u8 is not None else None,
+            sig.ctypes.data if sig is not None else None, C.byref(st)))
+        return f32, u8, sig, st
+
+    # ---- device-pointer building blocks (multi-GPU; pointers are ints, e.g. tensor.data_ptr()) ----
+    def render_tiles_device(self, cam: Camera, d_compact: int, d_sig: Optional[int] = None, seed: int = 1,
+                            rank: int = 0, world: int = 1, stream: Optional[int] = None,
+                            variant: int = abi.MI_VARIANT_DEFAULT):
+        pod = cam.to_pod()
+        opts = abi.mi_render_opts(seed=seed, rank=rank, world=world, variant=variant,
+                                  want_signature=int(d_sig is not None))
+        st = abi.mi_stats()
+        abi.check(self._lib.mi_render_tiles_device(self._h, C.byref(pod), C.byref(opts), d_compact, d_sig,
+                                                   stream, C.byref(st)))
+        return st
+
+    def unpermute_device(self, cam: Camera, world: int, d_gathered: int, d_image: int, stream: Optional[int] = None):
+        pod = cam.to_pod()
+        abi.check(self._lib.mi_unpermute_device(self._h, C.byref(pod), world, d_gathered, d_image, stream))
+
+    def tonemap_device(self, cam: Camera, d_image_f32: int, d_image_u8: int, stream: Optional[int] = None):
+        pod = cam.to_pod()
+        abi.check(self._lib.mi_tonemap_device(self._h, C.byref(pod), d_image_f32, d_image_u8, stream))
+
+    def last_kernel_ms(self) -> float:
+        ms = C.c_float()
+        abi.check(self._lib.mi_last_kernel_ms(self._h, C.byref(ms)))
+        return float(ms.value)
+
+
+def compact_size(cam: Camera, world: int):
+    """(tiles_total, tiles_padded) of the tile partition (mi_compact_size)."""
+    pod = cam.to_pod()
+    a, b = C.c_uint32(), C.c_uint32()
+    abi.check(abi.load().mi_compact_size(C.byref(pod), world, C.byref(a), C.byref(b)))
+    return int(a.value), int(b.value)
+
+
+@dataclass
+class Scene:                         # tracing.rs:213-218
+    camera: Camera
+    objects: List[Intersectable]
+    point_light_pos: tuple = (0.0, 1.0, 5.0)    # Phong only (debug mode, not accelerated)
+    ambient: tuple = (0.1, 0.1, 0.1)            # Phong only
+
+    def flatten(self) -> FlatScene:
+        fb = FlatBuilder()
+        for obj in self.objects:
+            obj.flatten(fb)
+        return fb.finish()
+
+    def render_to_image(self, seed: int = 1, device: int = 0) -> np.ndarray:
+        """Scene::render_to_image (tracing.rs:221-263): returns the RgbImage bytes [H,W,3] u8."""
+        ctx = Context(device)
+        try:
+            ctx.upload(self.flatten())
+            _, u8, _, _ = ctx.render(self.camera, seed=seed, want_f32=False, want_u8=True)
+            return u8
+        finally:
+            ctx.close()

@@ -1,0 +1,242 @@
+/*
+ * mi_rt.h — C ABI of the MI355X path-tracing hot path (libmi_rt.so).
+ *
+ * This header is the drop-in boundary for ONE path of mbk6/CS397RayTracingSP22:
+ *     Scene::render_to_image()            src/util/tracing.rs:221-263
+ *       -> Camera::generate_rays()        src/util/tracing.rs:159-209
+ *       -> Scene::shade_ray()             src/util/tracing.rs:300-324
+ *       -> Scene::intersect_ray()         src/util/tracing.rs:326-346
+ *            -> {Sphere,Triangle,Plane,ConvexVolume,StaticMesh}::intersect_ray
+ *                                         src/util/geometry.rs:300-321, 394-413, 430-450, 473-489, 501-526
+ *            -> BVHNode / AABB / IndexedTriangle   src/util/geometry.rs:50-79, 93-119, 330-366
+ *       -> Material::scatter()/emission() src/util/materials.rs:33-48, 56-71, 77-104, 113-149, 158-166
+ *       -> Texture::sample()              src/util/texture.rs:26-32
+ *
+ * The reference has no FFI of its own (it is one Rust crate; the path is reached by
+ * ordinary calls through `dyn Intersectable` / `dyn Material`).  What crosses this
+ * boundary is therefore the *flattened* form of the reference's own structs: every
+ * struct below mirrors one reference struct field for field, and `mi_scene_desc.objects`
+ * keeps the order of `Scene.objects` (tracing.rs:215) because that order decides ties
+ * (tracing.rs:335, strict `<`: the first object wins) and the order of RNG draws made by
+ * ConvexVolume::intersect_ray (geometry.rs:517).
+ *
+ * Plain C: pointers, sizes, PODs.  No torch / HIP types in any signature; device
+ * pointers and streams travel as `void*`.  Nothing unwinds across this boundary:
+ * every entry point returns an mi_status and records a message for mi_last_error().
+ *
+ * Ownership: every input array is borrowed for the duration of the call only
+ * (mi_scene_upload copies to the device).  Output buffers are allocated by the caller.
+ * A mi_ctx owns its device memory; it is not re-entrant, distinct contexts may be
+ * used from distinct threads.
+ *
+ * All arithmetic on the path is f32 (Vec3 = Vector3<f32>, tracing.rs:22).
+ */
+#ifndef MI_RT_H
+#define MI_RT_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI_RT_ABI_VERSION 1
+
+/* ---- status codes (reference: panics via assert!/expect/unwrap, geometry.rs:149-151) ---- */
+typedef enum mi_status {
+    MI_OK               =  0,
+    MI_ERR_INVALID      = -1,  /* NULL pointer, bad index, bad size                      */
+    MI_ERR_UNSUPPORTED  = -2,  /* reference feature outside the accelerated path         */
+    MI_ERR_NO_DEVICE    = -3,  /* no gfx950 device / HIP runtime failure at create       */
+    MI_ERR_HIP          = -4,  /* a HIP call failed (message holds hipGetErrorString)    */
+    MI_ERR_OOM          = -5,
+    MI_ERR_NO_SCENE     = -6   /* render called before a scene was uploaded              */
+} mi_status;
+
+/* ---- materials: `trait Material` implementors, materials.rs:20,51,74,107,152 ---- */
+typedef enum mi_material_kind {
+    MI_MAT_LAMBERTIAN    = 0,  /* Lambertian{albedo, emission}                      :20  */
+    MI_MAT_METAL         = 1,  /* Metal{albedo, emission, roughness}                :51  */
+    MI_MAT_DIELECTRIC    = 2,  /* Dielectric{idx_of_refraction}                     :74  */
+    MI_MAT_PARAMETERIZED = 3,  /* ParameterizedMaterial{albedo,emission,rough,metal}:107 */
+    MI_MAT_ISOTROPIC     = 4   /* Isotropic{albedo, emission}                       :152 */
+} mi_material_kind;
+
+typedef struct mi_material {
+    int32_t kind;              /* mi_material_kind */
+    float   albedo[3];
+    float   emission[3];
+    float   roughness;
+    float   metallic;
+    float   idx_of_refraction;
+} mi_material;                 /* 40 bytes */
+
+/* ---- primitives: `trait Intersectable` implementors, geometry.rs:389,424,468,495,127 ---- */
+typedef enum mi_object_kind {
+    MI_OBJ_SPHERE   = 0,       /* Sphere{center, radius, material}          geometry.rs:389 */
+    MI_OBJ_TRIANGLE = 1,       /* Triangle{a, b, c, material}               geometry.rs:424 */
+    MI_OBJ_PLANE    = 2,       /* Plane{point, normal, material}            geometry.rs:468 */
+    MI_OBJ_VOLUME   = 3,       /* ConvexVolume{boundary, phase_function, density}      :495 */
+    MI_OBJ_MESH     = 4        /* StaticMesh                                geometry.rs:127 */
+} mi_object_kind;
+
+/* One entry of Scene.objects (tracing.rs:215), in the reference's order. */
+typedef struct mi_object {
+    int32_t kind;              /* mi_object_kind                         */
+    int32_t index;             /* index into the typed array of that kind */
+} mi_object;
+
+typedef struct mi_sphere   { float center[3]; float radius; int32_t material; } mi_sphere;
+typedef struct mi_triangle { float a[3]; float b[3]; float c[3]; int32_t material; } mi_triangle;
+typedef struct mi_plane    { float point[3]; float normal[3]; int32_t material; } mi_plane;
+
+/* ConvexVolume (geometry.rs:495-500).  `boundary` is `Arc<dyn Intersectable>` in the
+ * reference; every use in the reference (tracing.rs:499-516) and every config is a
+ * Sphere, and that is the boundary kind this ABI carries.  The boundary sphere's own
+ * material is ignored by the reference ("arbitrary", tracing.rs:503). */
+typedef struct mi_volume {
+    float   boundary_center[3];
+    float   boundary_radius;
+    float   density;
+    int32_t phase_material;    /* index of the phase-function material (Isotropic) */
+} mi_volume;
+
+/* Texture (texture.rs:12-14) after `get_pixel(..).to_rgb()`: tightly packed RGB8,
+ * row 0 = top row of the image file.  Decoding image files is load-time work outside
+ * this path (texture.rs:16-25). */
+typedef struct mi_texture {
+    int32_t        width;
+    int32_t        height;
+    const uint8_t* rgb;        /* width*height*3 bytes */
+} mi_texture;
+
+/* StaticMesh (geometry.rs:127-134).  Geometry is tobj's single-index `Mesh`
+ * (geometry.rs:140-148): one index per corner into positions/normals/texcoords.
+ * normals and texcoords are required: the reference indexes them on every candidate
+ * hit (geometry.rs:350,355) and would panic without them. */
+typedef struct mi_mesh {
+    const float*    positions;      /* n_vertices*3 */
+    const float*    normals;        /* n_vertices*3 */
+    const float*    texcoords;      /* n_vertices*2 */
+    const uint32_t* indices;        /* n_triangles*3 */
+    int32_t         n_vertices;
+    int32_t         n_triangles;
+    float           transform[16];      /* cgmath Matrix4, column-major     geometry.rs:132 */
+    float           inv_transform[16];  /* transform.inverse_transform()    geometry.rs:168 */
+    int32_t         material;           /* index, or -1 = material from textures (:255)     */
+    int32_t         textures[5];        /* 0 albedo 1 emission 2 metallic 3 roughness 4 normal; -1 = None (:130) */
+} mi_mesh;
+
+typedef struct mi_scene_desc {
+    const mi_object*   objects;    int32_t n_objects;
+    const mi_sphere*   spheres;    int32_t n_spheres;
+    const mi_triangle* triangles;  int32_t n_triangles;
+    const mi_plane*    planes;     int32_t n_planes;
+    const mi_volume*   volumes;    int32_t n_volumes;
+    const mi_mesh*     meshes;     int32_t n_meshes;
+    const mi_material* materials;  int32_t n_materials;
+    const mi_texture*  textures;   int32_t n_textures;
+} mi_scene_desc;
+
+/* ---- Camera (tracing.rs:138-155), field for field ---- */
+#define MI_PROJ_ORTHOGRAPHIC 0    /* CameraProjectionMode::Orthographic — MI_ERR_UNSUPPORTED */
+#define MI_PROJ_PERSPECTIVE  1
+#define MI_SHADE_PHONG       0    /* ShadingMode::Phong (debug)         — MI_ERR_UNSUPPORTED */
+#define MI_SHADE_PATHTRACE   1
+
+typedef struct mi_camera_desc {
+    float    eyepoint[3];
+    float    view_dir[3];
+    float    up[3];
+    int32_t  projection_mode;
+    int32_t  shading_mode;
+    uint32_t path_depth;
+    uint32_t path_samples;      /* must be 1 on the GPU path (every config; tracing.rs:370) */
+    uint32_t screen_width;
+    uint32_t screen_height;
+    float    focal_length;
+    float    focus_dist;
+    float    lens_radius;
+    uint32_t aa_sample_count;   /* perfect square (tracing.rs:152) */
+    float    max_trace_dist;
+    float    gamma;
+} mi_camera_desc;
+
+/* ---- render options (new: the reference RNG is unseeded thread_rng) ---- */
+#define MI_TILE 32              /* image tiles are MI_TILE x MI_TILE pixels */
+
+typedef struct mi_render_opts {
+    uint32_t seed;              /* RNG stream key: (seed, y*W+x, sample)                 */
+    int32_t  rank;              /* this process renders tiles t with t % world == rank   */
+    int32_t  world;             /* number of ranks sharing the image (>=1)               */
+    int32_t  variant;           /* 0 = default kernel; see mi_variant                    */
+    int32_t  want_signature;    /* 1 = also produce per-pixel path signatures (diagnostic) */
+} mi_render_opts;
+
+typedef enum mi_variant {
+    MI_VARIANT_DEFAULT = 0,     /* library picks (currently MI_VARIANT_PARKED)            */
+    MI_VARIANT_SIMPLE  = 1,     /* one segment per loop trip, mesh traversal in line      */
+    MI_VARIANT_PARKED  = 2      /* __ballot-voted phases: mesh rays parked and traversed together */
+} mi_variant;
+
+typedef struct mi_stats {
+    uint64_t samples;           /* camera rays (paths) traced by this call                */
+    uint64_t pixels;            /* pixels owned by this rank                              */
+    uint32_t tiles;             /* tiles owned by this rank                               */
+    uint32_t tiles_padded;      /* ceil(total_tiles/world): slots in the compact buffer   */
+    float    kernel_ms;         /* path-tracing kernel, HIP events on the launch stream   */
+    float    total_ms;          /* whole call incl. un-permute / tone-map / copies        */
+    uint32_t scene_bytes;       /* bytes of scene data resident on device                 */
+    uint32_t scene_in_lds;      /* 1 if the mesh BVH was staged into LDS                  */
+} mi_stats;
+
+typedef struct mi_ctx mi_ctx;
+
+/* Create a context on HIP device `device` (one process per GPU: pass LOCAL_RANK). */
+int  mi_ctx_create(int device, mi_ctx** out);
+void mi_ctx_destroy(mi_ctx* ctx);
+
+/* Flatten + upload a scene: replaces the construction of `Scene.objects`
+ * (tracing.rs:374-540) and StaticMesh::build_bvh (geometry.rs:175-217; the BVH is
+ * rebuilt here with the reference's topology). */
+int  mi_scene_upload(mi_ctx* ctx, const mi_scene_desc* scene);
+
+/* Replaces Scene::render_to_image (tracing.rs:221-263) for a whole image on one GPU.
+ * out_rgb_f32: W*H*3 linear per-pixel means BEFORE saturation/gamma (parity surface), may be NULL.
+ * out_rgb_u8 : W*H*3, the RgbImage byte layout of tracing.rs:226,254-256, may be NULL.
+ * out_sig    : W*H u32 path signatures when opts->want_signature, may be NULL.
+ * Host pointers. opts->rank/world must be 0/1. */
+int  mi_render(mi_ctx* ctx, const mi_camera_desc* cam, const mi_render_opts* opts,
+               float* out_rgb_f32, uint8_t* out_rgb_u8, uint32_t* out_sig, mi_stats* stats);
+
+/* Multi-GPU building blocks; all pointers are DEVICE pointers on ctx's device and
+ * `stream` is a hipStream_t (NULL = default stream).  Nothing is synchronised: work is
+ * queued on `stream`.
+ *
+ * mi_render_tiles_device: rank `opts->rank` of `opts->world` renders its tiles
+ *   (tile t -> rank t % world, slot t / world) into a compact tile-major buffer
+ *   d_compact[tiles_padded][MI_TILE*MI_TILE][3] f32 (row-major inside a tile; pixels
+ *   outside the image are written as 0).  d_sig (may be NULL) is [tiles_padded][MI_TILE*MI_TILE] u32.
+ * mi_unpermute_device: gathered buffer [world][tiles_padded][1024][3] -> row-major W*H*3 f32.
+ * mi_tonemap_device: tracing.rs:244-256 (saturate toward white, gamma, quantise) -> W*H*3 u8. */
+int  mi_compact_size(const mi_camera_desc* cam, int32_t world, uint32_t* tiles_total, uint32_t* tiles_padded);
+int  mi_render_tiles_device(mi_ctx* ctx, const mi_camera_desc* cam, const mi_render_opts* opts,
+                            void* d_compact_f32, void* d_sig_u32, void* stream, mi_stats* stats);
+int  mi_unpermute_device(mi_ctx* ctx, const mi_camera_desc* cam, int32_t world,
+                         const void* d_gathered_f32, void* d_image_f32, void* stream);
+int  mi_tonemap_device(mi_ctx* ctx, const mi_camera_desc* cam,
+                       const void* d_image_f32, void* d_image_u8, void* stream);
+
+/* Elapsed time of the most recent path-tracing kernel of this ctx (HIP events on its
+ * launch stream); synchronises on the stop event. */
+int  mi_last_kernel_ms(mi_ctx* ctx, float* ms);
+
+/* Thread-local message of the most recent failure in this thread. */
+const char* mi_last_error(void);
+int  mi_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI_RT_H */

@@ -1,0 +1,192 @@
+/*
+ * orc_math.h — TEST INFRASTRUCTURE (oracle).  Not product code: nothing under
+ * cs397raytracingsp22_amd/ may include, link or call anything in oracle/.
+ *
+ * Restates the arithmetic of the third-party crates the reference path leans on.
+ * Their sources are NOT under /root/reference (Cargo.lock pins: cgmath 0.18.0,
+ * rand 0.8.4); the semantics below are restated from the crates' documented public
+ * behaviour — PARITY UNPINNED on this point (see DESIGN.md "Oracle").
+ *
+ *   cgmath 0.18.0  Vector3 ops, InnerSpace::{dot,magnitude2,magnitude,normalize},
+ *                  cross, Matrix3*Vector3, Matrix4::{transform_point,transform_vector,
+ *                  transpose}, Basis3::between_vectors (quaternion shortest arc)
+ *   rand   0.8.4   Rng::gen_range for f32 half-open ranges and u32 ranges
+ *
+ * Every expression is written in the evaluation order Rust gives it (Rust never
+ * contracts a*b+c into an FMA); build with -ffp-contract=off.
+ */
+#ifndef ORC_MATH_H
+#define ORC_MATH_H
+
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+typedef struct { float x, y, z; } v3;
+typedef struct { float x, y; } v2;
+typedef struct { v3 c0, c1, c2; } m3;         /* column-major, like cgmath Matrix3 */
+
+static inline v3 v3_make(float x, float y, float z) { v3 r = { x, y, z }; return r; }
+static inline v3 v3_zero(void) { return v3_make(0.0f, 0.0f, 0.0f); }
+static inline v3 v3_add(v3 a, v3 b) { return v3_make(a.x + b.x, a.y + b.y, a.z + b.z); }
+static inline v3 v3_sub(v3 a, v3 b) { return v3_make(a.x - b.x, a.y - b.y, a.z - b.z); }
+static inline v3 v3_neg(v3 a) { return v3_make(-a.x, -a.y, -a.z); }
+/* Vector3 * S and S * Vector3: component-wise product */
+static inline v3 v3_scale(v3 a, float s) { return v3_make(a.x * s, a.y * s, a.z * s); }
+/* Vector3 / S: component-wise division (not multiply-by-reciprocal) */
+static inline v3 v3_divs(v3 a, float s) { return v3_make(a.x / s, a.y / s, a.z / s); }
+static inline v3 v3_mul_elem(v3 a, v3 b) { return v3_make(a.x * b.x, a.y * b.y, a.z * b.z); }
+/* InnerSpace::dot = mul_element_wise(..).sum() = (x + y) + z */
+static inline float v3_dot(v3 a, v3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+static inline v3 v3_cross(v3 a, v3 b) {
+    return v3_make(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+static inline float v3_mag2(v3 a) { return v3_dot(a, a); }
+static inline float v3_mag(v3 a) { return sqrtf(v3_mag2(a)); }
+/* InnerSpace::normalize = normalize_to(1) = self * (1 / self.magnitude()) */
+static inline v3 v3_normalize(v3 a) { return v3_scale(a, 1.0f / v3_mag(a)); }
+static inline float v3_get(v3 a, int axis) { return axis == 0 ? a.x : (axis == 1 ? a.y : a.z); }
+
+static inline v2 v2_make(float x, float y) { v2 r = { x, y }; return r; }
+
+/* Matrix3 * Vector3 = c0*v.x + c1*v.y + c2*v.z (vector adds left to right) */
+static inline v3 m3_mul_v3(m3 m, v3 v) {
+    return v3_add(v3_add(v3_scale(m.c0, v.x), v3_scale(m.c1, v.y)), v3_scale(m.c2, v.z));
+}
+
+/* Matrix4 (column-major float[16]): m[col*4 + row]. */
+/* Transform3::transform_vector: (M * v.extend(0)).truncate() */
+static inline v3 m4_transform_vector(const float* m, v3 v) {
+    v3 r;
+    r.x = ((m[0] * v.x + m[4] * v.y) + m[8]  * v.z) + m[12] * 0.0f;
+    r.y = ((m[1] * v.x + m[5] * v.y) + m[9]  * v.z) + m[13] * 0.0f;
+    r.z = ((m[2] * v.x + m[6] * v.y) + m[10] * v.z) + m[14] * 0.0f;
+    return r;
+}
+/* Transform3::transform_point: Point3::from_homogeneous(M * p.to_homogeneous());
+ * from_homogeneous multiplies xyz by (1 / w). */
+static inline v3 m4_transform_point(const float* m, v3 p) {
+    float x = ((m[0] * p.x + m[4] * p.y) + m[8]  * p.z) + m[12] * 1.0f;
+    float y = ((m[1] * p.x + m[5] * p.y) + m[9]  * p.z) + m[13] * 1.0f;
+    float z = ((m[2] * p.x + m[6] * p.y) + m[10] * p.z) + m[14] * 1.0f;
+    float w = ((m[3] * p.x + m[7] * p.y) + m[11] * p.z) + m[15] * 1.0f;
+    float iw = 1.0f / w;
+    return v3_make(x * iw, y * iw, z * iw);
+}
+/* (M^T).transform_vector(v): row/col swapped */
+static inline v3 m4_transpose_transform_vector(const float* m, v3 v) {
+    v3 r;
+    r.x = ((m[0] * v.x + m[1] * v.y) + m[2]  * v.z) + m[3]  * 0.0f;
+    r.y = ((m[4] * v.x + m[5] * v.y) + m[6]  * v.z) + m[7]  * 0.0f;
+    r.z = ((m[8] * v.x + m[9] * v.y) + m[10] * v.z) + m[11] * 0.0f;
+    return r;
+}
+
+/* approx::ulps_eq!(a, b) for f32 with the default epsilon = f32::EPSILON, max_ulps = 4 */
+static inline int orc_ulps_eq(float a, float b) {
+    if (fabsf(a - b) <= 1.1920929e-07f) return 1;
+    if ((a < 0.0f) != (b < 0.0f)) return 0;       /* differing signs */
+    int32_t ia, ib;
+    memcpy(&ia, &a, 4); memcpy(&ib, &b, 4);
+    int64_t d = (int64_t)ia - (int64_t)ib;
+    if (d < 0) d = -d;
+    return d <= 4;
+}
+
+/* cgmath Basis3::between_vectors(a, b) = Matrix3::from(Quaternion::between_vectors(a, b)):
+ * the shortest-arc rotation taking a to b ("half-way quaternion"):
+ *   same direction      (a.b ~ 1, ulps_eq)        -> identity
+ *   opposite direction  (a.b / k ~ -1)            -> pi rotation about normalize(a x unit_x)
+ *                                                    (a x unit_y if that is ~0)
+ *   otherwise           normalize(Quaternion{s: k + a.b, v: a x b}),  k = sqrt(|a|^2 |b|^2)
+ * followed by cgmath's quaternion -> Matrix3 conversion. */
+static inline m3 orc_between_vectors(v3 a, v3 b) {
+    float qs, qx, qy, qz;
+    float k_cos_theta = v3_dot(a, b);
+    if (orc_ulps_eq(k_cos_theta, 1.0f)) {
+        qs = 1.0f; qx = 0.0f; qy = 0.0f; qz = 0.0f;
+    } else {
+        float k = sqrtf(v3_mag2(a) * v3_mag2(b));
+        if (orc_ulps_eq(k_cos_theta / k, -1.0f)) {
+            v3 orthogonal = v3_cross(a, v3_make(1.0f, 0.0f, 0.0f));
+            if (orc_ulps_eq(v3_mag2(orthogonal), 0.0f))
+                orthogonal = v3_cross(a, v3_make(0.0f, 1.0f, 0.0f));
+            orthogonal = v3_normalize(orthogonal);
+            qs = 0.0f; qx = orthogonal.x; qy = orthogonal.y; qz = orthogonal.z;
+        } else {
+            v3 c = v3_cross(a, b);
+            float s = k + k_cos_theta;
+            /* Quaternion::normalize: self * (1 / magnitude), magnitude2 = s*s + v.v */
+            float mag = sqrtf(s * s + v3_dot(c, c));
+            float inv = 1.0f / mag;
+            qs = s * inv; qx = c.x * inv; qy = c.y * inv; qz = c.z * inv;
+        }
+    }
+    /* impl From<Quaternion> for Matrix3 */
+    float x2 = qx + qx, y2 = qy + qy, z2 = qz + qz;
+    float xx2 = x2 * qx, xy2 = x2 * qy, xz2 = x2 * qz;
+    float yy2 = y2 * qy, yz2 = y2 * qz, zz2 = z2 * qz;
+    float sy2 = y2 * qs, sz2 = z2 * qs, sx2 = x2 * qs;
+    m3 m;
+    m.c0 = v3_make(1.0f - yy2 - zz2, xy2 + sz2, xz2 - sy2);
+    m.c1 = v3_make(xy2 - sz2, 1.0f - xx2 - zz2, yz2 + sx2);
+    m.c2 = v3_make(xz2 + sy2, yz2 - sx2, 1.0f - xx2 - yy2);
+    return m;
+}
+
+/* f32::powi(n) for the two exponents the path uses (tracing.rs:60-61, materials.rs:81):
+ * LLVM expands a constant powi by square-and-multiply. */
+static inline float orc_powi2(float a) { return a * a; }
+static inline float orc_powi5(float a) { float a2 = a * a; float a4 = a2 * a2; return a * a4; }
+
+/* f32::clamp(min, max) */
+static inline float orc_clampf(float v, float lo, float hi) {
+    if (v < lo) v = lo;
+    if (v > hi) v = hi;
+    return v;
+}
+/* f32::signum: 1.0 for +0.0 and positives, -1.0 for -0.0 and negatives, NaN for NaN */
+static inline float orc_signum(float v) {
+    if (v != v) return v;
+    return signbit(v) ? -1.0f : 1.0f;
+}
+
+/* Natural logarithm used for the free-flight distance (geometry.rs:517, f32::ln).
+ * The reference calls the platform libm; its RNG is unseeded, so only the
+ * distribution matters.  This restatement fixes ONE sequence of f32 operations so a
+ * second implementation can match it bit for bit; it agrees with libm logf to 2 ulp
+ * (tests/test_oracle_math.py sweeps it).  Cephes-style: x = m*2^e, m in
+ * [sqrt(1/2), sqrt(2)), log(m) by a degree-8 polynomial in (m-1). */
+static inline float orc_logf(float x) {
+    if (!(x > 0.0f)) return (x == 0.0f) ? -INFINITY : NAN;
+    if (x == INFINITY) return x;
+    uint32_t ix; memcpy(&ix, &x, 4);
+    int e = 0;
+    if (ix < 0x00800000u) {                 /* subnormal: scale by 2^23 */
+        x = x * 8388608.0f; memcpy(&ix, &x, 4); e = -23;
+    }
+    e += (int)(ix >> 23) - 126;             /* x = m * 2^e, m in [0.5, 1) */
+    ix = (ix & 0x007fffffu) | 0x3f000000u;
+    float m; memcpy(&m, &ix, 4);
+    if (m < 0.70710678f) { e = e - 1; m = m + m; }
+    float f = m - 1.0f;
+    float z = f * f;
+    float p = 7.0376836292e-2f;
+    p = p * f + -1.1514610310e-1f;
+    p = p * f + 1.1676998740e-1f;
+    p = p * f + -1.2420140846e-1f;
+    p = p * f + 1.4249322787e-1f;
+    p = p * f + -1.6668057665e-1f;
+    p = p * f + 2.0000714765e-1f;
+    p = p * f + -2.4999993993e-1f;
+    p = p * f + 3.3333331174e-1f;
+    float y = (f * z) * p;
+    float fe = (float)e;
+    y = y + fe * -2.12194440e-4f;
+    y = y - 0.5f * z;
+    float r = f + y;
+    r = r + fe * 0.693359375f;
+    return r;
+}
+
+#endif /* ORC_MATH_H */

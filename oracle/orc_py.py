@@ -1,0 +1,211 @@
+"""ctypes binding of the ORACLE (oracle/_build/liborc.so) — TEST INFRASTRUCTURE.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this
+module; the product package (cs397raytracingsp22_amd/) never does.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+from cs397raytracingsp22_amd import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_build", "liborc.so")
+
+
+class orc_counters(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in (
+        "samples", "segments", "object_tests", "mesh_tests", "mesh_entered", "mesh_hits",
+        "box_tests", "tri_tests", "texel_fetches", "rng_draws")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+class orc_hit_rec(C.Structure):
+    _fields_ = [("hit", C.c_int32), ("distance", C.c_float), ("hitpoint", abi.f3), ("normal", abi.f3),
+                ("frontface", C.c_int32), ("object", C.c_int32), ("material", abi.mi_material),
+                ("uv", C.c_float * 2), ("has_uv", C.c_int32)]
+
+
+def build(force=False):
+    """Compile the oracle with gcc (oracle/Makefile)."""
+    if force or not os.path.exists(LIB_PATH):
+        subprocess.run(["make", "-C", _HERE] + (["-B"] if force else []), check=True, capture_output=True)
+
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build()
+        lib = C.CDLL(LIB_PATH)
+        vp = C.c_void_p
+        fp = C.POINTER(C.c_float)
+        lib.orc_scene_create.argtypes = [C.POINTER(abi.mi_scene_desc), C.POINTER(vp)]
+        lib.orc_scene_destroy.argtypes = [vp]
+        lib.orc_scene_destroy.restype = None
+        lib.orc_render.argtypes = [vp, C.POINTER(abi.mi_camera_desc), C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int,
+                                   C.c_int, vp, vp, vp, C.POINTER(orc_counters)]
+        lib.orc_intersect.argtypes = [vp, fp, fp, C.c_float, C.c_float, C.c_uint32, C.c_uint32, C.c_uint32,
+                                      C.POINTER(orc_hit_rec)]
+        lib.orc_generate_rays.argtypes = [C.POINTER(abi.mi_camera_desc), C.c_uint32, C.c_uint32, C.c_uint32, vp]
+        lib.orc_shade.argtypes = [vp, C.POINTER(abi.mi_camera_desc), fp, fp, C.c_uint32, C.c_uint32, C.c_uint32, fp]
+        lib.orc_scatter.argtypes = [C.POINTER(abi.mi_material), fp, fp, C.c_int, fp, C.c_uint32, C.c_uint32,
+                                    C.c_uint32, fp]
+        lib.orc_reflect.argtypes = [fp, fp, fp]
+        lib.orc_reflect.restype = None
+        lib.orc_refract.argtypes = [fp, fp, C.c_float, fp]
+        lib.orc_refract.restype = None
+        lib.orc_fresnel.argtypes = [fp, fp, C.c_float]
+        lib.orc_fresnel.restype = C.c_float
+        lib.orc_texture_sample.argtypes = [C.POINTER(abi.mi_texture), C.c_float, C.c_float, fp]
+        lib.orc_texture_sample.restype = None
+        lib.orc_between_vectors_mat.argtypes = [fp, fp, fp]
+        lib.orc_between_vectors_mat.restype = None
+        lib.orc_logf_export.argtypes = [C.c_float]
+        lib.orc_logf_export.restype = C.c_float
+        lib.orc_tonemap_pixel.argtypes = [fp, C.c_float, C.POINTER(C.c_uint8)]
+        lib.orc_tonemap_pixel.restype = None
+        lib.orc_rng_words.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, vp]
+        lib.orc_rng_words.restype = None
+        lib.orc_bvh_stats.argtypes = [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        _lib = lib
+    return _lib
+
+
+def _f3(v):
+    return (C.c_float * 3)(*[float(x) for x in v])
+
+
+class OracleScene:
+    """An orc_scene built from the same flattened description the product consumes."""
+
+    def __init__(self, flat):
+        self._lib = load()
+        self._flat = flat
+        self._h = C.c_void_p()
+        rc = self._lib.orc_scene_create(C.byref(flat.desc), C.byref(self._h))
+        if rc != 0:
+            raise RuntimeError(f"orc_scene_create failed: {rc}")
+
+    def close(self):
+        if self._h:
+            self._lib.orc_scene_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def render(self, cam, seed=1, threads=None, window=None, want_u8=True, want_sig=True, want_counters=False):
+        """orc_render over window=(x0, y0, w, h) (default: whole image).
+        Returns (f32 [h,w,3], u8 [h,w,3] | None, sig [h,w] | None, counters dict | None)."""
+        pod = cam.to_pod()
+        x0, y0, w, h = window if window is not None else (0, 0, cam.screen_width, cam.screen_height)
+        f32 = np.empty((h, w, 3), np.float32)
+        u8 = np.empty((h, w, 3), np.uint8) if want_u8 else None
+        sig = np.empty((h, w), np.uint32) if want_sig else None
+        cnt = orc_counters() if want_counters else None
+        threads = threads or min(os.cpu_count() or 1, 64)
+        rc = self._lib.orc_render(self._h, C.byref(pod), seed, threads, x0, y0, w, h, f32.ctypes.data,
+                                  u8.ctypes.data if u8 is not None else None,
+                                  sig.ctypes.data if sig is not None else None,
+                                  C.byref(cnt) if cnt is not None else None)
+        if rc != 0:
+            raise RuntimeError(f"orc_render failed: {rc}")
+        return f32, u8, sig, (cnt.as_dict() if cnt is not None else None)
+
+    def intersect(self, origin, direction, t_min=0.001, t_max=100.0, seed=1, pixel=0, sample=0):
+        rec = orc_hit_rec()
+        rc = self._lib.orc_intersect(self._h, _f3(origin), _f3(direction), t_min, t_max, seed, pixel, sample, C.byref(rec))
+        if rc != 0:
+            raise RuntimeError(f"orc_intersect failed: {rc}")
+        return rec
+
+    def shade(self, cam, origin, direction, seed=1, pixel=0, sample=0):
+        pod = cam.to_pod()
+        out = (C.c_float * 3)()
+        rc = self._lib.orc_shade(self._h, C.byref(pod), _f3(origin), _f3(direction), seed, pixel, sample, out)
+        if rc != 0:
+            raise RuntimeError(f"orc_shade failed: {rc}")
+        return np.array(out[:], np.float32)
+
+    def bvh_stats(self, mesh=0):
+        a, b, c = C.c_int(), C.c_int(), C.c_int()
+        rc = self._lib.orc_bvh_stats(self._h, mesh, C.byref(a), C.byref(b), C.byref(c))
+        if rc != 0:
+            raise RuntimeError("orc_bvh_stats failed")
+        return a.value, b.value, c.value
+
+
+def generate_rays(cam, x, y, seed=1):
+    pod = cam.to_pod()
+    out = np.empty((cam.aa_sample_count, 6), np.float32)
+    rc = load().orc_generate_rays(C.byref(pod), seed, x, y, out.ctypes.data)
+    if rc != 0:
+        raise RuntimeError(f"orc_generate_rays failed: {rc}")
+    return out
+
+
+def scatter(material, hitpoint, normal, frontface, ray_dir, seed=1, pixel=0, sample=0):
+    pod = material.to_pod()
+    out = (C.c_float * 7)()
+    load().orc_scatter(C.byref(pod), _f3(hitpoint), _f3(normal), int(frontface), _f3(ray_dir), seed, pixel, sample, out)
+    a = np.array(out[:], np.float32)
+    return a[0:3], a[3:6], float(a[6])
+
+
+def reflect(v, n):
+    out = (C.c_float * 3)()
+    load().orc_reflect(_f3(v), _f3(n), out)
+    return np.array(out[:], np.float32)
+
+
+def refract(v, n, eta):
+    out = (C.c_float * 3)()
+    load().orc_refract(_f3(v), _f3(n), eta, out)
+    return np.array(out[:], np.float32)
+
+
+def fresnel(v, n, ir):
+    return float(load().orc_fresnel(_f3(v), _f3(n), ir))
+
+
+def texture_sample(tex, u, v):
+    t = abi.mi_texture()
+    t.width, t.height = tex.width, tex.height
+    t.rgb = tex.img.ctypes.data_as(C.POINTER(C.c_uint8))
+    out = (C.c_float * 3)()
+    load().orc_texture_sample(C.byref(t), u, v, out)
+    return np.array(out[:], np.float32)
+
+
+def between_vectors(a, b):
+    out = (C.c_float * 9)()
+    load().orc_between_vectors_mat(_f3(a), _f3(b), out)
+    return np.array(out[:], np.float32).reshape(3, 3).T      # rows x cols
+
+
+def logf(x):
+    return float(load().orc_logf_export(float(x)))
+
+
+def tonemap_pixel(rgb, gamma=2.0):
+    out = (C.c_uint8 * 3)()
+    load().orc_tonemap_pixel(_f3(rgb), gamma, out)
+    return np.array(out[:], np.uint8)
+
+
+def rng_words(seed, pixel, sample, n):
+    out = np.empty(n, np.uint32)
+    load().orc_rng_words(seed, pixel, sample, n, out.ctypes.data)
+    return out

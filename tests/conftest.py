@@ -1,0 +1,31 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def orc():
+    """The CPU oracle (oracle/_build/liborc.so), built on demand with gcc."""
+    from oracle import orc_py
+    orc_py.build()
+    orc_py.load()
+    return orc_py
+
+
+@pytest.fixture(scope="session")
+def gpu_ctx():
+    """One mi_ctx on GPU 0 through the C ABI.  Fails (does not skip) when the HIP library
+    or the device is missing: -m gpu tests must exercise the native path."""
+    from cs397raytracingsp22_amd import Context
+    ctx = Context(0)
+    yield ctx
+    ctx.close()
