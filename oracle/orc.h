@@ -55,9 +55,11 @@ void orc_scene_destroy(orc_scene* s);
  *   out_rgb_f32 : w*h*3 per-pixel mean radiance BEFORE saturation/gamma (may be NULL)
  *   out_rgb_u8  : w*h*3 bytes as tracing.rs:254-256 writes them      (may be NULL)
  *   out_sig     : w*h path signatures (DESIGN.md "Path signature")   (may be NULL)
- *   n_threads   : row-parallel workers (mirrors rayon's per-row tasks, tracing.rs:228) */
+ *   n_threads   : row-parallel workers (mirrors rayon's per-row tasks, tracing.rs:228)
+ *   row_stride  : window row k is image row y0 + k*row_stride (1 = contiguous window);
+ *                 > 1 samples the whole image height with few rows (bench.py cpu_baseline) */
 int  orc_render(const orc_scene* s, const mi_camera_desc* cam, uint32_t seed, int n_threads,
-                int x0, int y0, int w, int h,
+                int x0, int y0, int w, int h, int row_stride,
                 float* out_rgb_f32, uint8_t* out_rgb_u8, uint32_t* out_sig, orc_counters* counters);
 
 /* ---- unit-level entry points for known-answer tests ---- */

@@ -31,6 +31,13 @@ class orc_hit_rec(C.Structure):
                 ("uv", C.c_float * 2), ("has_uv", C.c_int32)]
 
 
+def usable_cores():
+    try:
+        return max(1, min(len(os.sched_getaffinity(0)), 256))
+    except AttributeError:
+        return max(1, min(os.cpu_count() or 1, 256))
+
+
 def build(force=False):
     """Compile the oracle with gcc (oracle/Makefile)."""
     if force or not os.path.exists(LIB_PATH):
@@ -52,7 +59,7 @@ def load():
         lib.orc_scene_destroy.argtypes = [vp]
         lib.orc_scene_destroy.restype = None
         lib.orc_render.argtypes = [vp, C.POINTER(abi.mi_camera_desc), C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int,
-                                   C.c_int, vp, vp, vp, C.POINTER(orc_counters)]
+                                   C.c_int, C.c_int, vp, vp, vp, C.POINTER(orc_counters)]
         lib.orc_intersect.argtypes = [vp, fp, fp, C.c_float, C.c_float, C.c_uint32, C.c_uint32, C.c_uint32,
                                       C.POINTER(orc_hit_rec)]
         lib.orc_generate_rays.argtypes = [C.POINTER(abi.mi_camera_desc), C.c_uint32, C.c_uint32, C.c_uint32, vp]
@@ -106,8 +113,10 @@ class OracleScene:
         except Exception:
             pass
 
-    def render(self, cam, seed=1, threads=None, window=None, want_u8=True, want_sig=True, want_counters=False):
-        """orc_render over window=(x0, y0, w, h) (default: whole image).
+    def render(self, cam, seed=1, threads=None, window=None, want_u8=True, want_sig=True, want_counters=False,
+               row_stride=1):
+        """orc_render over window=(x0, y0, w, h) (default: whole image); window row k is image
+        row y0 + k*row_stride.
         Returns (f32 [h,w,3], u8 [h,w,3] | None, sig [h,w] | None, counters dict | None)."""
         pod = cam.to_pod()
         x0, y0, w, h = window if window is not None else (0, 0, cam.screen_width, cam.screen_height)
@@ -115,8 +124,8 @@ class OracleScene:
         u8 = np.empty((h, w, 3), np.uint8) if want_u8 else None
         sig = np.empty((h, w), np.uint32) if want_sig else None
         cnt = orc_counters() if want_counters else None
-        threads = threads or min(os.cpu_count() or 1, 64)
-        rc = self._lib.orc_render(self._h, C.byref(pod), seed, threads, x0, y0, w, h, f32.ctypes.data,
+        threads = threads or usable_cores()
+        rc = self._lib.orc_render(self._h, C.byref(pod), seed, threads, x0, y0, w, h, row_stride, f32.ctypes.data,
                                   u8.ctypes.data if u8 is not None else None,
                                   sig.ctypes.data if sig is not None else None,
                                   C.byref(cnt) if cnt is not None else None)

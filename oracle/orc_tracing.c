@@ -121,19 +121,26 @@ static inline void sig_hit(orc_path* p, const orc_rayhit* h) {
     uint32_t tb; memcpy(&tb, &h->distance, 4);
     p->sig = orc_lowbias32((p->sig ^ tb) + (uint32_t)(h->object + 1) * 0x9e3779b1u);
 }
-static inline void sig_end(orc_path* p) {
+/* a path that leaves the scene folds the final RNG state in (it pins every draw made so
+ * far); a path cut by path_depth does not, because the draws of its last scatter
+ * (tracing.rs:312 at depth-1) can no longer influence the image and an implementation
+ * may skip that scatter */
+static inline void sig_end_miss(orc_path* p) {
     p->sig = orc_lowbias32(p->sig ^ p->rng.s0 ^ orc_rotl32(p->rng.s1, 16));
+}
+static inline void sig_end_depth(orc_path* p) {
+    p->sig = orc_lowbias32(p->sig ^ 0x5bd1e995u);
 }
 
 /* ---- Scene::shade_ray :300-324 (recursive, as the reference) ---- */
 static v3 shade_ray(const orc_scene* s, const mi_camera_desc* cam, const orc_ray* ray, uint32_t recursion_depth, orc_path* p) {
     if (recursion_depth >= cam->path_depth) {                         /* :301 */
-        sig_end(p);
+        sig_end_depth(p);
         return background_color(ray->direction);                      /* :302 */
     }
     orc_rayhit hit;
     if (!orc_scene_intersect_ray(s, ray, 0.001f, cam->max_trace_dist, p, &hit)) {   /* :305 */
-        sig_end(p);
+        sig_end_miss(p);
         return background_color(ray->direction);                      /* :306 */
     }
     sig_hit(p, &hit);
@@ -189,7 +196,7 @@ static void render_pixel(const orc_scene* s, const mi_camera_desc* cam, uint32_t
 /* ---- Scene::render_to_image :221-263: rows are the parallel unit (:228) ---- */
 typedef struct {
     const orc_scene* s; const mi_camera_desc* cam; uint32_t seed;
-    int x0, y0, w, h;
+    int x0, y0, w, h, row_stride;
     float* out_f32; uint8_t* out_u8; uint32_t* out_sig;
     int* next_row; pthread_mutex_t* lock;
     orc_counters cnt; int want_cnt;
@@ -204,7 +211,7 @@ static void* render_worker(void* arg) {
         if (row >= j->h) break;
         for (int cx = 0; cx < j->w; cx++) {                           /* :229 */
             size_t k = (size_t)row * j->w + cx;
-            render_pixel(j->s, j->cam, j->seed, (uint32_t)(j->x0 + cx), (uint32_t)(j->y0 + row),
+            render_pixel(j->s, j->cam, j->seed, (uint32_t)(j->x0 + cx), (uint32_t)(j->y0 + row * j->row_stride),
                          j->out_f32 ? j->out_f32 + 3 * k : NULL, j->out_u8 ? j->out_u8 + 3 * k : NULL,
                          j->out_sig ? j->out_sig + k : NULL, j->want_cnt ? &j->cnt : NULL);
         }
@@ -222,11 +229,13 @@ static int check_camera(const mi_camera_desc* cam) {
 }
 
 int orc_render(const orc_scene* s, const mi_camera_desc* cam, uint32_t seed, int n_threads,
-               int x0, int y0, int w, int h,
+               int x0, int y0, int w, int h, int row_stride,
                float* out_rgb_f32, uint8_t* out_rgb_u8, uint32_t* out_sig, orc_counters* counters) {
     int rc = check_camera(cam);
     if (rc != MI_OK || !s) return rc != MI_OK ? rc : MI_ERR_INVALID;
-    if (x0 < 0 || y0 < 0 || w < 0 || h < 0 || (uint32_t)(x0 + w) > cam->screen_width || (uint32_t)(y0 + h) > cam->screen_height)
+    if (row_stride < 1) return MI_ERR_INVALID;
+    if (x0 < 0 || y0 < 0 || w < 0 || h < 0 || (uint32_t)(x0 + w) > cam->screen_width ||
+        (h > 0 && (uint32_t)(y0 + (h - 1) * row_stride) >= cam->screen_height))
         return MI_ERR_INVALID;
     if (n_threads < 1) n_threads = 1;
     if (n_threads > 256) n_threads = 256;
@@ -236,7 +245,7 @@ int orc_render(const orc_scene* s, const mi_camera_desc* cam, uint32_t seed, int
     pthread_t* th = (pthread_t*)calloc((size_t)n_threads, sizeof(pthread_t));
     for (int t = 0; t < n_threads; t++) {
         render_job* j = &jobs[t];
-        j->s = s; j->cam = cam; j->seed = seed; j->x0 = x0; j->y0 = y0; j->w = w; j->h = h;
+        j->s = s; j->cam = cam; j->seed = seed; j->x0 = x0; j->y0 = y0; j->w = w; j->h = h; j->row_stride = row_stride;
         j->out_f32 = out_rgb_f32; j->out_u8 = out_rgb_u8; j->out_sig = out_sig;
         j->next_row = &next_row; j->lock = &lock; j->want_cnt = counters != NULL;
     }
