@@ -25,6 +25,13 @@ def load_asset_mesh(name: str) -> objload.Mesh:
     return objload.Mesh(z["positions"], z["normals"], z["texcoords"], z["indices"], name)
 
 
+def load_asset_textures():
+    """RGB8 decodes of the reference's texture/{green.png, magenta.jpg, normal_test.jpg, normal_test.png}
+    (tools/make_assets.py), keyed as head_scene expects."""
+    z = np.load(os.path.join(ASSETS, "textures.npz"), allow_pickle=False)
+    return {k: Texture(z[k]) for k in z.files}
+
+
 def _quad(p0, p1, p2, p3, material):
     """Two `Triangle`s (geometry.rs:424), counter-clockwise seen from inside the box."""
     return [Triangle(p0, p1, p2, material), Triangle(p0, p2, p3, material)]

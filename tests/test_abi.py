@@ -1,0 +1,70 @@
+"""The C-ABI library loads and exports every symbol include/mi_rt.h declares; the ctypes
+mirror has the C layout; the product fails loudly (no CPU fallback) without a GPU.
+No compute calls here: CPU-only."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "mi_rt.h")
+
+
+def declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(mi_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_header_declares_expected_entry_points():
+    from cs397raytracingsp22_amd import abi
+    assert declared_functions() == sorted(abi.EXPORTS)
+
+
+def test_library_exports_every_declared_symbol():
+    from cs397raytracingsp22_amd import abi
+    lib = abi.load()
+    for name in declared_functions():
+        assert hasattr(lib, name), name
+    assert lib.mi_abi_version() == 1
+
+
+def test_ctypes_layout_matches_c(tmp_path):
+    from cs397raytracingsp22_amd import abi
+    names = ["mi_material", "mi_object", "mi_sphere", "mi_triangle", "mi_plane", "mi_volume", "mi_texture", "mi_mesh",
+             "mi_scene_desc", "mi_camera_desc", "mi_render_opts", "mi_stats"]
+    prog = '#include <stdio.h>\n#include "mi_rt.h"\nint main(void){' + "".join(
+        f'printf("{n} %zu\\n", sizeof({n}));' for n in names) + "return 0;}\n"
+    src = tmp_path / "sz.c"
+    src.write_text(prog)
+    exe = tmp_path / "sz"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout
+    sizes = dict(line.split() for line in out.strip().splitlines())
+    for n in names:
+        assert C.sizeof(getattr(abi, n)) == int(sizes[n]), n
+
+
+def test_no_cpu_fallback_without_gpu():
+    """On a box without a GPU the product must fail loudly, never render on the CPU."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from cs397raytracingsp22_amd import Context, abi
+    with pytest.raises(abi.MiError) as ei:
+        Context(0)
+    assert ei.value.code == abi.MI_ERR_NO_DEVICE
+    assert "no CPU fallback" in str(ei.value)
+
+
+def test_product_never_imports_oracle():
+    """oracle/ is test infrastructure: nothing in the product package may reference it."""
+    pkg = os.path.join(ROOT, "cs397raytracingsp22_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h", ".hpp", ".sh")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "orc_" not in text and "liborc" not in text and "from oracle" not in text and "import oracle" not in text, f

@@ -1,0 +1,52 @@
+"""Golden fixtures (tests/golden/*.npz, made by tools/make_golden.py with the oracle).
+CPU: the oracle reproduces them bit for bit.  GPU (-m gpu): the HIP path reproduces them
+through the C ABI without the oracle in the loop — signatures bit-exact, radiance within
+the tolerances stated in tests/test_gpu_parity.py."""
+import os
+
+import numpy as np
+import pytest
+
+from cs397raytracingsp22_amd import scenes
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+CASES = {
+    "cfg1_400x400_16spp": lambda: scenes.config1(400, 400, 16, 8),
+    "cfg2_1080p_256spp": lambda: scenes.config2(1920, 1080, 256, 10),
+    "cfg2_defocus_480x270_16spp": lambda: scenes.config2(480, 270, 16, 10, lens_radius=0.05),
+    "cfg4_drone_480x270_16spp": lambda: scenes.config4(480, 270, 16, 10, tex_size=256),
+    "cfg5_subsurface_480x270_64spp_d50": lambda: scenes.config5(480, 270, 64, 50),
+    "head_200x200_16spp": lambda: scenes.head_scene(200, 200, 16, 10, textures=scenes.load_asset_textures()),
+}
+
+
+def load(name):
+    z = np.load(os.path.join(GOLD, name + ".npz"), allow_pickle=False)
+    return z["f32"], z["u8"], z["sig"], tuple(int(v) for v in z["window"]), int(z["seed"])
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_oracle_reproduces_golden(orc, name):
+    f32, u8, sig, win, seed = load(name)
+    sc = CASES[name]()
+    g32, g8, gsig, _ = orc.OracleScene(sc.flatten()).render(sc.camera, seed=seed, window=win)
+    assert np.array_equal(gsig, sig)
+    assert np.array_equal(g32, f32)
+    assert np.array_equal(g8, u8)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_gpu_reproduces_golden(gpu_ctx, name):
+    f32, u8, sig, (x0, y0, w, h), seed = load(name)
+    sc = CASES[name]()
+    gpu_ctx.upload(sc.flatten())
+    g32, g8, gsig, _ = gpu_ctx.render(sc.camera, seed=seed, want_sig=True)
+    g32, g8, gsig = g32[y0:y0 + h, x0:x0 + w], g8[y0:y0 + h, x0:x0 + w], gsig[y0:y0 + h, x0:x0 + w]
+    bad = int((gsig != sig).sum())
+    assert bad == 0, f"{bad}/{sig.size} pixels took a different path than the golden run"
+    rms = np.sqrt(np.mean((g32.astype(np.float64) - f32) ** 2, axis=(0, 1)))
+    assert float(rms.max()) <= 1e-3                                        # north_star tolerance
+    assert float((np.abs(g32.astype(np.float64) - f32) / np.maximum(1.0, np.abs(f32))).max()) <= 2e-5
+    assert int(np.abs(g8.astype(int) - u8.astype(int)).max()) <= 1

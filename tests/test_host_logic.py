@@ -1,0 +1,136 @@
+"""Host-side logic above the C ABI (CPU only): OBJ reader (tobj semantics), cgmath helpers,
+scene flattening order, tile partition arithmetic and the N>1 gather path on gloo."""
+import os
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+
+from cs397raytracingsp22_amd import (Camera, ConvexVolume, Dielectric, Isotropic, Lambertian, Scene, Sphere, StaticMesh,
+                                     Triangle, abi, cgmath, dist, objload, scenes)
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF_OBJ = "/root/reference/obj"
+
+
+def test_obj_reader_fan_triangulation_and_single_index():
+    text = textwrap.dedent("""
+        v 0 0 0
+        v 1 0 0
+        v 1 1 0
+        v 0 1 0
+        v 0.5 2 0
+        vt 0 0
+        vt 1 0
+        vt 1 1
+        vt 0 1
+        vn 0 0 1
+        f 1/1/1 2/2/1 3/3/1 4/4/1 5/3/1
+        f 1/1/1 3/3/1 -1/4/1
+    """)
+    m = objload.load_obj_text(text)[0]
+    # pentagon -> fan (0,k,k+1): 3 triangles; + 1 triangle
+    assert m.n_triangles == 4
+    idx = m.indices.reshape(-1, 3)
+    assert idx[0].tolist() == [0, 1, 2] and idx[1].tolist() == [0, 2, 3] and idx[2].tolist() == [0, 3, 4]
+    # (v5, vt3) and (v5, vt4) are different single-index vertices; negative index = last vertex
+    assert m.n_vertices == 6
+    assert np.allclose(m.positions.reshape(-1, 3)[idx[3][2]], [0.5, 2, 0])
+    assert np.allclose(m.texcoords.reshape(-1, 2)[idx[3][2]], [0, 1])
+
+
+def test_obj_reader_keeps_first_model_only():
+    text = "v 0 0 0\nv 1 0 0\nv 0 1 0\nvt 0 0\nvn 0 0 1\ng a\nf 1/1/1 2/1/1 3/1/1\ng b\nf 3/1/1 2/1/1 1/1/1\nf 1/1/1 2/1/1 3/1/1\n"
+    models = objload.load_obj_text(text)
+    assert [m.n_triangles for m in models] == [1, 2]            # the reference uses models.remove(0) (geometry.rs:157)
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_OBJ), reason="reference assets not present (GPU box)")
+@pytest.mark.parametrize("name,tris", [("teapot", 240), ("cube", 12), ("drone", 1736), ("sphere", 32512)])
+def test_committed_assets_equal_reader_output(name, tris):
+    m = objload.load_obj(os.path.join(REF_OBJ, name + ".obj"))[0]
+    a = scenes.load_asset_mesh(name)
+    assert m.n_triangles == tris == a.n_triangles
+    assert np.array_equal(m.positions, a.positions) and np.array_equal(m.indices, a.indices)
+    assert np.array_equal(m.normals, a.normals) and np.array_equal(m.texcoords, a.texcoords)
+
+
+def test_cgmath_conventions():
+    T = cgmath.from_translation((1, 2, 3))
+    assert np.allclose(cgmath.cols16(T)[12:15], [1, 2, 3])       # column-major: translation in column 3
+    R = cgmath.from_angle_x(90.0)
+    assert np.allclose(R @ np.float32([0, 1, 0, 0]), [0, 0, 1, 0], atol=1e-6)     # right-handed, M*v
+    Ry = cgmath.from_angle_y(90.0)
+    assert np.allclose(Ry @ np.float32([0, 0, 1, 0]), [1, 0, 0, 0], atol=1e-6)
+    M = cgmath.mul(T, R, cgmath.from_scale(2.0))
+    assert np.allclose(M @ cgmath.inverse_transform(M), np.eye(4), atol=1e-5)
+
+
+def test_flatten_keeps_scene_object_order_and_shares_materials():
+    red = Lambertian(albedo=(1, 0, 0))
+    objs = [Sphere((0, 0, 0), 1, red), Triangle((0, 0, 0), (1, 0, 0), (0, 1, 0), red),
+            ConvexVolume(Sphere((0, 0, 0), 2, Dielectric(1.5)), Isotropic(), 0.5), Sphere((1, 1, 1), 1, Dielectric(1.3))]
+    d = Scene(Camera(), objs).flatten().desc
+    assert [(d.objects[i].kind, d.objects[i].index) for i in range(d.n_objects)] == [(0, 0), (1, 0), (3, 0), (0, 1)]
+    assert d.n_materials == 3 and d.spheres[0].material == d.triangles[0].material
+    with pytest.raises(abi.MiError):
+        Scene(Camera(), [ConvexVolume(Triangle((0, 0, 0), (1, 0, 0), (0, 1, 0), red), Isotropic(), 1.0)]).flatten()
+
+
+def test_tile_partition_arithmetic():
+    W, H = 75, 41                                                # ragged: 3 x 2 tiles
+    tx, ty, total = dist.tile_grid(W, H)
+    assert (tx, ty, total) == (3, 2, 6)
+    for world in (1, 2, 4, 5, 8):
+        padded = dist.tiles_padded(W, H, world)
+        owned = [dist.tiles_of_rank(W, H, r, world) for r in range(world)]
+        assert sorted(sum(owned, [])) == list(range(total))      # a partition
+        assert max(len(o) for o in owned) == padded
+        rank, idx = dist.compact_index(W, H, world)
+        assert idx.max() < padded * dist.TILE_PIXELS
+        # (rank, idx) is injective over the image
+        key = rank.astype(np.int64) * padded * dist.TILE_PIXELS + idx
+        assert np.unique(key).size == W * H
+
+
+GLOO_WORKER = """
+import os, sys
+sys.path.insert(0, {root!r})
+import numpy as np, torch, torch.distributed as dist
+from cs397raytracingsp22_amd import dist as pdist
+rank = int(os.environ["RANK"]); world = int(os.environ["WORLD_SIZE"])
+dist.init_process_group(backend="gloo")
+W, H = 75, 41
+rng = np.random.default_rng(5)
+image = rng.random((H, W, 3)).astype(np.float32)          # the frame every rank would agree on
+r_of, idx = pdist.compact_index(W, H, world)
+padded = pdist.tiles_padded(W, H, world)
+local = np.zeros((padded * pdist.TILE_PIXELS, 3), np.float32)
+mine = r_of == rank
+local[idx[mine]] = image[mine]                            # what K1 writes for this rank's tiles
+g = pdist.gather_compact(torch.from_numpy(local.reshape(padded, pdist.TILE_PIXELS, 3)), world, rank)
+if rank == 0:
+    flat = g.numpy().reshape(world, -1, 3)
+    out = flat[r_of, idx]                                 # K3's mapping (numpy checker)
+    assert np.array_equal(out, image), "gathered frame differs"
+    print("GLOO_OK", world)
+else:
+    assert g is None
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_gather_path_world_size_2_gloo(tmp_path):
+    """N > 1 host path on CPU: tile ownership, the frame's single gather (gloo here, RCCL on
+    the GPU box) and the un-permute mapping reassemble the image exactly."""
+    script = tmp_path / "w.py"
+    script.write_text(GLOO_WORKER.format(root=ROOT))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29517")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29517", str(script)],
+                         capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "GLOO_OK 2" in out.stdout

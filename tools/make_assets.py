@@ -24,3 +24,17 @@ for name in ("teapot", "cube", "drone", "sphere"):
                         texcoords=m.texcoords, indices=m.indices)
     print(f"{name}: models={len(models)} vertices={m.n_vertices} triangles={m.n_triangles} "
           f"normals={m.normals.size // 3} texcoords={m.texcoords.size // 2}")
+
+# textures the reference's own run() scene binds (tracing.rs:387-401): decoded here with PIL
+# (image-file decoding is load-time work outside the path) and stored as RGB8 arrays.
+try:
+    from PIL import Image
+    tex = {}
+    for key, fn in (("green", "green.png"), ("magenta", "magenta.jpg"), ("normal_test_jpg", "normal_test.jpg"),
+                    ("normal_test_png", "normal_test.png")):
+        with Image.open(os.path.join(REF, "texture", fn)) as im:
+            tex[key] = np.asarray(im.convert("RGB"))
+        print(f"texture {key}: {tex[key].shape}")
+    np.savez_compressed(os.path.join(OUT, "textures.npz"), **tex)
+except ImportError:
+    print("PIL missing: textures.npz not regenerated")
