@@ -18,6 +18,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -30,6 +31,8 @@
 namespace pt {
 hipError_t launch_megakernel(const K1Args& args, uint32_t n_blocks, bool lds, bool park, bool sig,
                              size_t lds_bytes, hipStream_t stream);
+hipError_t launch_megakernel_voted(const K1Args& args, uint32_t n_blocks, bool lds, bool sig, bool diag,
+                                   size_t lds_bytes, hipStream_t stream);
 hipError_t launch_unpermute(const float* gathered, float* image, uint32_t width, uint32_t height, uint32_t tiles_x,
                             uint32_t world, uint32_t tiles_padded, hipStream_t stream);
 hipError_t launch_sig_unpermute(const uint32_t* gathered, uint32_t* image, uint32_t width, uint32_t height,
@@ -87,6 +90,8 @@ struct mi_ctx {
     uint8_t* d_u8 = nullptr;    size_t u8_bytes = 0;
     uint32_t* d_sigc = nullptr; size_t sigc_bytes = 0;
     uint32_t* d_sigi = nullptr; size_t sigi_bytes = 0;
+    unsigned long long* d_diag = nullptr;    // 8 counters of the diagnostic variant
+    uint32_t vote_t = 1, vote_a = 1, k_steps = 32;
 };
 
 static int ensure(void** p, size_t* have, size_t want) {
@@ -120,6 +125,13 @@ extern "C" int mi_ctx_create(int device, mi_ctx** out) {
     HIP_TRY(hipStreamCreate(&c->stream));
     HIP_TRY(hipEventCreate(&c->ev_start));
     HIP_TRY(hipEventCreate(&c->ev_stop));
+    HIP_TRY(hipMalloc((void**)&c->d_diag, 8 * sizeof(unsigned long long)));
+    // developer knobs of the voted kernel (defaults are the tuned values)
+    if (const char* e = getenv("MI_RT_VOTE_T")) c->vote_t = (uint32_t)atoi(e);
+    if (const char* e = getenv("MI_RT_VOTE_A")) c->vote_a = (uint32_t)atoi(e);
+    if (const char* e = getenv("MI_RT_KSTEPS")) c->k_steps = (uint32_t)atoi(e);
+    if (c->vote_t < 1) c->vote_t = 1;
+    if (c->k_steps < 1) c->k_steps = 1;
     *out = c;
     return MI_OK;
 }
@@ -134,6 +146,7 @@ extern "C" void mi_ctx_destroy(mi_ctx* c) {
     if (c->d_u8) (void)hipFree(c->d_u8);
     if (c->d_sigc) (void)hipFree(c->d_sigc);
     if (c->d_sigi) (void)hipFree(c->d_sigi);
+    if (c->d_diag) (void)hipFree(c->d_diag);
     if (c->ev_start) (void)hipEventDestroy(c->ev_start);
     if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -464,12 +477,21 @@ static int render_tiles(mi_ctx* c, const mi_camera_desc* cam, const mi_render_op
     a.seed_key = lowbias32(o->seed ^ 0x68e31da4u);
     a.out = d_compact;
     a.sig = (o->want_signature && d_sig) ? d_sig : nullptr;
-    int variant = o->variant == MI_VARIANT_DEFAULT ? MI_VARIANT_PARKED : o->variant;
-    if (variant != MI_VARIANT_SIMPLE && variant != MI_VARIANT_PARKED) return fail(MI_ERR_INVALID, "unknown variant %d", o->variant);
+    int variant = o->variant == MI_VARIANT_DEFAULT ? MI_VARIANT_VOTED : o->variant;
+    if (variant < MI_VARIANT_SIMPLE || variant > MI_VARIANT_VOTED_DIAG) return fail(MI_ERR_INVALID, "unknown variant %d", o->variant);
     bool park = variant == MI_VARIANT_PARKED && c->S.n_meshes > 0;
+    a.R.vote_t = c->vote_t; a.R.vote_a = c->vote_a; a.R.k_steps = c->k_steps;
+    a.diag = nullptr;
     uint32_t n_blocks = padded * (uint32_t)kBlocksPerTile;
+    if (variant == MI_VARIANT_VOTED_DIAG) {
+        a.diag = c->d_diag;
+        HIP_TRY(hipMemsetAsync(c->d_diag, 0, 8 * sizeof(unsigned long long), stream));
+    }
     HIP_TRY(hipEventRecord(c->ev_start, stream));
-    HIP_TRY(launch_megakernel(a, n_blocks, lds, park, a.sig != nullptr, c->lds_bytes, stream));
+    if (variant == MI_VARIANT_VOTED || variant == MI_VARIANT_VOTED_DIAG)
+        HIP_TRY(launch_megakernel_voted(a, n_blocks, lds, a.sig != nullptr, variant == MI_VARIANT_VOTED_DIAG, c->lds_bytes, stream));
+    else
+        HIP_TRY(launch_megakernel(a, n_blocks, lds, park, a.sig != nullptr, c->lds_bytes, stream));
     HIP_TRY(hipEventRecord(c->ev_stop, stream));
     c->ev_recorded = true;
     if (st) {
@@ -521,6 +543,14 @@ extern "C" int mi_last_kernel_ms(mi_ctx* c, float* ms) {
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipEventSynchronize(c->ev_stop));
     HIP_TRY(hipEventElapsedTime(ms, c->ev_start, c->ev_stop));
+    return MI_OK;
+}
+
+extern "C" int mi_last_diag(mi_ctx* c, uint64_t* out8) {
+    if (!c || !out8) return fail(MI_ERR_INVALID, "mi_last_diag: bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out8, c->d_diag, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return MI_OK;
 }
 

@@ -132,6 +132,8 @@ struct DRender {
     uint32_t my_tiles;       // tiles owned by this rank
     uint32_t lds_nodes;      // number of BVH nodes staged into LDS (0 = read from global)
     uint32_t lds_tris;       // number of triangles staged into LDS
+    uint32_t vote_t, vote_a; // VOTED kernel: run the BVH phase when n_trav*vote_t >= n_a*vote_a
+    uint32_t k_steps;        // VOTED kernel: node micro-steps per BVH trip
 };
 
 // kernel argument block of K1 (passed by value: lives in the kernarg segment / SGPRs)
@@ -142,6 +144,7 @@ struct K1Args {
     uint32_t seed_key;   // lowbias32(seed ^ 0x68e31da4)
     float*    out;       // [tiles_padded][1024][3]
     uint32_t* sig;       // [tiles_padded][1024] or nullptr
+    unsigned long long* diag;   // 8 counters (diagnostic build only) or nullptr
 };
 
 }  // namespace pt

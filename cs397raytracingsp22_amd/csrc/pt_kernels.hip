@@ -740,6 +740,221 @@ __global__ __launch_bounds__(kBlock) void pt_megakernel(K1Args A) {
     if (SIG && A.sig) A.sig[out_idx] = in_image ? sigsum : 0u;
 }
 
+// ---------------------------------------------------------------- K1, voted state machine
+// The divergent part of the path is the BVH walk: a ray that enters the teapot takes
+// 20..150 node steps, its 63 neighbours take 0.  Running the walk to completion inside
+// a segment (SIMPLE / PARKED above) makes the wave wait for its slowest lane.  Here the
+// scheduling unit is ONE NODE STEP.  Every lane is a small state machine:
+//     A     not inside a mesh: shade the pending hit, start a new sample if the path
+//           ended, walk the object list for the next segment, test the mesh root boxes
+//     TRAV  inside a mesh BVH: holds (node index, running best) in registers
+// and every trip of the wave-wide loop VOTES with __ballot/__popcll which phase to run:
+//     A-trip     when lanes in A are the majority,
+//     B-trip     otherwise: up to k_steps micro-steps, each again voted between the lanes
+//                that sit on an interior node (slab test) and those on a leaf (triangle test).
+// Lanes that are not in the voted phase keep their state and wait, so each instruction
+// stream runs with most of its lanes live, and lanes re-join the A phase as soon as THEIR
+// walk ends instead of when the slowest walk of the wave ends.
+// Order of evaluation per lane is unchanged (list objects in order, then meshes, DFS
+// left-then-right with one running bound), so results are bit-identical to SIMPLE.
+
+// find the next mesh (index >= m) whose root the ray enters; set up the walk registers.
+// returns false when no mesh is left.
+template <class BVH>
+__device__ __forceinline__ bool enter_next_mesh(const DScene& S, const BVH& B, int& m, f3 o, f3 d, float t_min, float t_max,
+                                                f3& oo, f3& od, f3& inv_d, int& ti, int& tend, int& ttb) {
+    for (; m < S.n_meshes; m++) {
+        const DMesh* M = &S.meshes[m];
+        oo = xform_point(M->inv_transform, o);                           // geometry.rs:304
+        od = xform_vector(M->inv_transform, d);
+        inv_d = mk3(1.0f / od.x, 1.0f / od.y, 1.0f / od.z);              // geometry.rs:57
+        float4 n0, n1;
+        B.node(M->node_begin, n0, n1);
+        tend = M->node_end; ttb = M->tri_begin;
+        if (__float_as_int(n1.w) >= 0) { ti = M->node_begin; return true; }          // root is a leaf (:95)
+        if (slab(mk3(n0.x, n0.y, n0.z), mk3(n1.x, n1.y, n1.z), oo, inv_d, t_min, t_max)) {   // root box (:103)
+            ti = M->node_begin + 1;                                      // root passed with bound t_max: go to its left child
+            return true;
+        }
+    }
+    return false;
+}
+
+template <bool LDS, bool SIG, bool DIAG>
+__global__ __launch_bounds__(kBlock) void pt_megakernel_voted(K1Args A) {
+    const DScene& S = A.S;
+    const DCamera& C = A.C;
+
+    Bvh<LDS> B;
+    if (LDS) {
+        const float4* gn = reinterpret_cast<const float4*>(S.nodes);
+        const float4* gt = reinterpret_cast<const float4*>(S.tris);
+        int nn = (int)A.R.lds_nodes * 2, nt = (int)A.R.lds_tris * 3;
+        for (int k = threadIdx.x; k < nn; k += kBlock) k1_lds[k] = gn[k];
+        for (int k = threadIdx.x; k < nt; k += kBlock) k1_lds[nn + k] = gt[k];
+        __syncthreads();
+        B.nodes = k1_lds; B.tris = k1_lds + nn;
+    } else {
+        B.nodes = reinterpret_cast<const float4*>(S.nodes);
+        B.tris = reinterpret_cast<const float4*>(S.tris);
+    }
+
+    const uint32_t slot = blockIdx.x / kBlocksPerTile;
+    const uint32_t sub = blockIdx.x % kBlocksPerTile;
+    const uint32_t tile = slot * (uint32_t)A.R.world + (uint32_t)A.R.rank;
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t in_x = wave * 8 + (lane & 7), in_y = sub * 8 + (lane >> 3);
+    const uint32_t out_idx = slot * kTilePixels + in_y * kTile + in_x;
+    uint32_t px = 0, py = 0;
+    bool in_image = false;
+    if (tile < A.R.tiles_total) {
+        px = (tile % A.R.tiles_x) * kTile + in_x;
+        py = (tile / A.R.tiles_x) * kTile + in_y;
+        in_image = (px < C.width) && (py < C.height);
+    }
+    const uint32_t pixel = py * C.width + px;
+    const float t_min = 0.001f, t_max = C.max_trace_dist;
+    const int vote_t = (int)A.R.vote_t, vote_a = (int)A.R.vote_a, k_steps = (int)A.R.k_steps;
+
+    f3 accum = mk3(0.0f, 0.0f, 0.0f);
+    uint32_t sigsum = 0, sample = 0;
+    const uint32_t spp = in_image ? C.spp : 0u;
+
+    Path P;
+    P.o = P.d = P.T = P.L = mk3(0.0f, 0.0f, 0.0f); P.depth = 0; P.sig = 0; P.rng.s0 = P.rng.s1 = 1u;
+    Best best; best.t = 0.0f; best.obj = -1; best.tri = -1; best.u = best.v = 0.0f;
+
+    enum : int { ST_A = 0, ST_TRAV = 1, ST_DEAD = 2 };
+    int state = ST_A;
+    bool fresh = true, pending = false;
+    // walk registers (state TRAV)
+    int tm = 0, ti = 0, tend = 0, ttb = 0, tbtri = -1;
+    f3 too = mk3(0.0f, 0.0f, 0.0f), tod = too, tinv = too;
+    float tbt = 0.0f, tbu = 0.0f, tbv = 0.0f;
+
+    unsigned long long dg_tripsA = 0, dg_lanesA = 0, dg_tripsI = 0, dg_lanesI = 0, dg_tripsL = 0, dg_lanesL = 0, dg_tripsB = 0;
+
+    while (true) {
+        const int nA = __popcll(__ballot(state == ST_A));
+        const int nT = __popcll(__ballot(state == ST_TRAV));
+        if (nA + nT == 0) break;
+        const bool run_b = (nT > 0) && (nT * vote_t >= nA * vote_a);
+
+        if (!run_b) {
+            if (DIAG) { dg_tripsA++; dg_lanesA += (unsigned long long)nA; }
+            if (state == ST_A) {
+                // ---- (a) Scene::shade_ray, one level, for the intersection found last trip ----
+                if (pending) {
+                    pending = false;
+                    bool end_path;
+                    if (best.obj < 0) {
+                        end_path = true;
+                        if (SIG) P.sig = sig_end_miss(P.sig, P.rng);
+                    } else {
+                        if (SIG) P.sig = sig_hit(P.sig, best.t, best.obj);
+                        Surf s;
+                        resolve_hit(S, best, P.o, P.d, s);
+                        P.L = mk3(P.L.x + P.T.x * s.emission.x, P.L.y + P.T.y * s.emission.y, P.L.z + P.T.z * s.emission.z);
+                        P.depth++;
+                        if (P.depth >= C.path_depth) {
+                            end_path = true;
+                            if (SIG) P.sig = sig_end_depth(P.sig);
+                        } else {
+                            f3 nd, w;
+                            scatter(s, P.d, P.rng, nd, w);
+                            P.o = s.p; P.d = nd;
+                            P.T = mk3(P.T.x * w.x, P.T.y * w.y, P.T.z * w.z);
+                            end_path = false;
+                        }
+                    }
+                    if (end_path) {
+                        accum = accum + P.L;
+                        if (SIG) sigsum += P.sig;
+                        sample++;
+                        fresh = true;
+                    }
+                }
+                // ---- (b) Camera::generate_rays for the next sample ----
+                if (fresh) {
+                    if (sample >= spp) state = ST_DEAD;
+                    else {
+                        rng_init(P.rng, A.seed_key, pixel, sample);
+                        generate_ray(C, px, py, sample, P.rng, P.o, P.d);
+                        P.T = mk3(1.0f, 1.0f, 1.0f); P.L = mk3(0.0f, 0.0f, 0.0f); P.depth = 0; P.sig = 0;
+                        fresh = false;
+                    }
+                }
+                // ---- (c) Scene::intersect_ray: the object list, then the mesh roots ----
+                if (state == ST_A) {
+                    best.obj = -1; best.t = 0.0f; best.tri = -1; best.u = best.v = 0.0f;
+                    for (int k = 0; k < S.n_objects; k++) {
+                        const DObject* ob = &S.objects[k];
+                        if (ob->kind != OBJ_MESH) test_object(ob, k, P.o, P.d, t_min, t_max, P.rng, best);
+                    }
+                    tm = 0;
+                    if (enter_next_mesh(S, B, tm, P.o, P.d, t_min, t_max, too, tod, tinv, ti, tend, ttb)) {
+                        state = ST_TRAV; tbt = t_max; tbtri = -1; tbu = tbv = 0.0f;
+                    } else {
+                        pending = true;
+                    }
+                }
+            }
+        } else {
+            if (DIAG) dg_tripsB++;
+            // ---- B-trip: BVHNode::intersect_ray (geometry.rs:94-119), k_steps voted micro-steps ----
+            for (int k = 0; k < k_steps; k++) {
+                const bool in_t = (state == ST_TRAV);
+                float4 n0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), n1 = n0;
+                int tri = -1;
+                if (in_t) { B.node(ti, n0, n1); tri = __float_as_int(n1.w); }
+                const bool at_leaf = in_t && tri >= 0, at_inner = in_t && tri < 0;
+                const int n_leaf = __popcll(__ballot(at_leaf)), n_inner = __popcll(__ballot(at_inner));
+                if (n_leaf + n_inner == 0) break;
+                if (n_inner >= n_leaf) {
+                    if (DIAG) { dg_tripsI++; dg_lanesI += (unsigned long long)n_inner; }
+                    if (at_inner) {
+                        bool hit = slab(mk3(n0.x, n0.y, n0.z), mk3(n1.x, n1.y, n1.z), too, tinv, t_min, tbt);   // :103
+                        ti = hit ? ti + 1 : __float_as_int(n0.w);
+                    }
+                } else {
+                    if (DIAG) { dg_tripsL++; dg_lanesL += (unsigned long long)n_leaf; }
+                    if (at_leaf) {
+                        f3 a, e1, e2;
+                        B.tri(ttb + tri, a, e1, e2);
+                        float t, u, v;
+                        if (tri_t(too, tod, a, e1, e2, t_min, tbt, t, u, v)) {                                  // :97
+                            tbt = t; tbtri = tri; tbu = u; tbv = v;
+                        }
+                        ti = ti + 1;
+                    }
+                }
+                if (in_t && ti >= tend) {
+                    // this mesh is done: StaticMesh::intersect_ray returns (geometry.rs:305-313)
+                    if (tbtri >= 0) consider(best, tbt, S.meshes[tm].object_index, tbtri, tbu, tbv);
+                    tm++;
+                    if (enter_next_mesh(S, B, tm, P.o, P.d, t_min, t_max, too, tod, tinv, ti, tend, ttb)) {
+                        tbt = t_max; tbtri = -1; tbu = tbv = 0.0f;
+                    } else {
+                        state = ST_A; pending = true;
+                    }
+                }
+            }
+        }
+    }
+
+    float n = (float)C.spp;
+    float* o3 = A.out + (size_t)out_idx * 3;
+    if (in_image) { o3[0] = accum.x / n; o3[1] = accum.y / n; o3[2] = accum.z / n; }
+    else { o3[0] = 0.0f; o3[1] = 0.0f; o3[2] = 0.0f; }
+    if (SIG && A.sig) A.sig[out_idx] = in_image ? sigsum : 0u;
+    if (DIAG && A.diag && lane == 0) {
+        atomicAdd(&A.diag[0], dg_tripsA); atomicAdd(&A.diag[1], dg_lanesA);
+        atomicAdd(&A.diag[2], dg_tripsI); atomicAdd(&A.diag[3], dg_lanesI);
+        atomicAdd(&A.diag[4], dg_tripsL); atomicAdd(&A.diag[5], dg_lanesL);
+        atomicAdd(&A.diag[6], dg_tripsB); atomicAdd(&A.diag[7], 1ull);
+    }
+}
+
 // ---------------------------------------------------------------- K3: un-permute
 // gathered[world][tiles_padded][1024][3] -> image[H][W][3].  One thread per pixel.
 __global__ __launch_bounds__(256) void fb_unpermute(const float* __restrict__ gathered, float* __restrict__ image,
@@ -801,6 +1016,17 @@ hipError_t launch_megakernel(const K1Args& args, uint32_t n_blocks, bool lds, bo
         else      { if (sig) PT_LAUNCH(false, false, true); else PT_LAUNCH(false, false, false); }
     }
 #undef PT_LAUNCH
+    return hipGetLastError();
+}
+
+hipError_t launch_megakernel_voted(const K1Args& args, uint32_t n_blocks, bool lds, bool sig, bool diag,
+                                   size_t lds_bytes, hipStream_t stream) {
+    dim3 grid(n_blocks), block(kBlock);
+#define PT_LAUNCH_V(L, G, D) hipLaunchKernelGGL((pt_megakernel_voted<L, G, D>), grid, block, (L) ? lds_bytes : 0, stream, args)
+    if (diag) { if (lds) PT_LAUNCH_V(true, true, true); else PT_LAUNCH_V(false, true, true); }
+    else if (lds) { if (sig) PT_LAUNCH_V(true, true, false); else PT_LAUNCH_V(true, false, false); }
+    else          { if (sig) PT_LAUNCH_V(false, true, false); else PT_LAUNCH_V(false, false, false); }
+#undef PT_LAUNCH_V
     return hipGetLastError();
 }
 

@@ -120,6 +120,13 @@ class Context:
         pod = cam.to_pod()
         abi.check(self._lib.mi_tonemap_device(self._h, C.byref(pod), d_image_f32, d_image_u8, stream))
 
+    def last_diag(self):
+        """Counters of the last MI_VARIANT_VOTED_DIAG launch as a dict (diagnostic)."""
+        out = (C.c_uint64 * 8)()
+        abi.check(self._lib.mi_last_diag(self._h, out))
+        k = ["a_trips", "a_lanes", "inner_trips", "inner_lanes", "leaf_trips", "leaf_lanes", "b_trips", "waves"]
+        return dict(zip(k, [int(v) for v in out]))
+
     def last_kernel_ms(self) -> float:
         ms = C.c_float()
         abi.check(self._lib.mi_last_kernel_ms(self._h, C.byref(ms)))

@@ -175,9 +175,11 @@ typedef struct mi_render_opts {
 } mi_render_opts;
 
 typedef enum mi_variant {
-    MI_VARIANT_DEFAULT = 0,     /* library picks (currently MI_VARIANT_PARKED)            */
-    MI_VARIANT_SIMPLE  = 1,     /* one segment per loop trip, mesh traversal in line      */
-    MI_VARIANT_PARKED  = 2      /* __ballot-voted phases: mesh rays parked and traversed together */
+    MI_VARIANT_DEFAULT    = 0,  /* library picks (currently MI_VARIANT_VOTED)                      */
+    MI_VARIANT_SIMPLE     = 1,  /* one segment per loop trip, mesh traversal in line               */
+    MI_VARIANT_PARKED     = 2,  /* mesh rays parked, traversed together when a __ballot vote says so */
+    MI_VARIANT_VOTED      = 3,  /* per-lane state machine; every BVH node step is a __ballot-voted phase */
+    MI_VARIANT_VOTED_DIAG = 4   /* VOTED + per-phase trip / active-lane counters (never timed)      */
 } mi_variant;
 
 typedef struct mi_stats {
@@ -231,6 +233,11 @@ int  mi_tonemap_device(mi_ctx* ctx, const mi_camera_desc* cam,
 /* Elapsed time of the most recent path-tracing kernel of this ctx (HIP events on its
  * launch stream); synchronises on the stop event. */
 int  mi_last_kernel_ms(mi_ctx* ctx, float* ms);
+
+/* Counters of the most recent MI_VARIANT_VOTED_DIAG launch (synchronises the device):
+ * out8 = { A trips, sum of lanes in A trips, interior-step trips, lanes, leaf-step trips,
+ *          lanes, B trips, waves }.  active-lane fraction of a phase = lanes / (64 * trips). */
+int  mi_last_diag(mi_ctx* ctx, uint64_t* out8);
 
 /* Thread-local message of the most recent failure in this thread. */
 const char* mi_last_error(void);
