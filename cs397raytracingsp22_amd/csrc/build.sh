@@ -9,7 +9,7 @@ mkdir -p "$OUT"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function ${MI_RT_EXTRA_FLAGS:-}"
 "$HIPCC" $FLAGS -c "$HERE/pt_kernels.hip" -o "$OUT/pt_kernels.o"
-"$HIPCC" $FLAGS -x hip -c "$HERE/mi_rt.cpp" -o "$OUT/mi_rt.o"
+"$HIPCC" $FLAGS -x hip --cuda-host-only -c "$HERE/mi_rt.cpp" -o "$OUT/mi_rt.o"
 "$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$OUT/libmi_rt.so" "$OUT/pt_kernels.o" "$OUT/mi_rt.o"
 rm -f "$OUT/pt_kernels.o" "$OUT/mi_rt.o"
 # C++ caller of the C ABI through the host mirror of the reference interface (host/*.hpp)

@@ -33,6 +33,9 @@ hipError_t launch_megakernel(const K1Args& args, uint32_t n_blocks, bool lds, bo
                              size_t lds_bytes, hipStream_t stream);
 hipError_t launch_megakernel_voted(const K1Args& args, uint32_t n_blocks, bool lds, bool sig, bool diag,
                                    size_t lds_bytes, hipStream_t stream);
+hipError_t launch_megakernel_pooled(const K1Args& args, uint32_t tiles_padded, bool lds, bool sig, bool diag,
+                                    size_t lds_bytes, hipStream_t stream);
+size_t pooled_park_bytes(uint32_t tiles_padded);
 hipError_t launch_unpermute(const float* gathered, float* image, uint32_t width, uint32_t height, uint32_t tiles_x,
                             uint32_t world, uint32_t tiles_padded, hipStream_t stream);
 hipError_t launch_sig_unpermute(const uint32_t* gathered, uint32_t* image, uint32_t width, uint32_t height,
@@ -91,6 +94,7 @@ struct mi_ctx {
     uint32_t* d_sigc = nullptr; size_t sigc_bytes = 0;
     uint32_t* d_sigi = nullptr; size_t sigi_bytes = 0;
     unsigned long long* d_diag = nullptr;    // 8 counters of the diagnostic variant
+    void* d_park = nullptr; size_t park_bytes = 0;   // parked path records of the POOLED kernel
     uint32_t vote_t = 1, vote_a = 1, k_steps = 32;
 };
 
@@ -147,6 +151,7 @@ extern "C" void mi_ctx_destroy(mi_ctx* c) {
     if (c->d_sigc) (void)hipFree(c->d_sigc);
     if (c->d_sigi) (void)hipFree(c->d_sigi);
     if (c->d_diag) (void)hipFree(c->d_diag);
+    if (c->d_park) (void)hipFree(c->d_park);
     if (c->ev_start) (void)hipEventDestroy(c->ev_start);
     if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -478,18 +483,28 @@ static int render_tiles(mi_ctx* c, const mi_camera_desc* cam, const mi_render_op
     a.out = d_compact;
     a.sig = (o->want_signature && d_sig) ? d_sig : nullptr;
     int variant = o->variant == MI_VARIANT_DEFAULT ? MI_VARIANT_VOTED : o->variant;
-    if (variant < MI_VARIANT_SIMPLE || variant > MI_VARIANT_VOTED_DIAG) return fail(MI_ERR_INVALID, "unknown variant %d", o->variant);
+    if (variant < MI_VARIANT_SIMPLE || variant > MI_VARIANT_POOLED_DIAG) return fail(MI_ERR_INVALID, "unknown variant %d", o->variant);
+    const bool pooled = variant == MI_VARIANT_POOLED || variant == MI_VARIANT_POOLED_DIAG;
+    const bool diag = variant == MI_VARIANT_VOTED_DIAG || variant == MI_VARIANT_POOLED_DIAG;
+    a.park = nullptr;
+    if (pooled) {
+        int rc2 = ensure(&c->d_park, &c->park_bytes, pooled_park_bytes(padded));
+        if (rc2 != MI_OK) return rc2;
+        a.park = (float4*)c->d_park;
+    }
     bool park = variant == MI_VARIANT_PARKED && c->S.n_meshes > 0;
     a.R.vote_t = c->vote_t; a.R.vote_a = c->vote_a; a.R.k_steps = c->k_steps;
     a.diag = nullptr;
     uint32_t n_blocks = padded * (uint32_t)kBlocksPerTile;
-    if (variant == MI_VARIANT_VOTED_DIAG) {
+    if (diag) {
         a.diag = c->d_diag;
         HIP_TRY(hipMemsetAsync(c->d_diag, 0, 8 * sizeof(unsigned long long), stream));
     }
     HIP_TRY(hipEventRecord(c->ev_start, stream));
-    if (variant == MI_VARIANT_VOTED || variant == MI_VARIANT_VOTED_DIAG)
-        HIP_TRY(launch_megakernel_voted(a, n_blocks, lds, a.sig != nullptr, variant == MI_VARIANT_VOTED_DIAG, c->lds_bytes, stream));
+    if (pooled)
+        HIP_TRY(launch_megakernel_pooled(a, padded, lds, a.sig != nullptr, diag, c->lds_bytes, stream));
+    else if (variant == MI_VARIANT_VOTED || variant == MI_VARIANT_VOTED_DIAG)
+        HIP_TRY(launch_megakernel_voted(a, n_blocks, lds, a.sig != nullptr, diag, c->lds_bytes, stream));
     else
         HIP_TRY(launch_megakernel(a, n_blocks, lds, park, a.sig != nullptr, c->lds_bytes, stream));
     HIP_TRY(hipEventRecord(c->ev_stop, stream));

@@ -15,6 +15,17 @@
 //    touched once per mesh HIT, not per candidate.
 #pragma once
 #include <stdint.h>
+#include <hip/hip_runtime.h>
+
+// Read-only scene data is typed as CONSTANT address space on the device: a read at a
+// wave-uniform address then compiles to a scalar (SMEM) load into SGPRs even when the kernel
+// also stores to global memory (with plain global pointers the compiler must assume the
+// stores may alias and falls back to per-lane vector loads).  Same 8-byte pointers on the host.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define PT_CONST_AS __attribute__((address_space(4)))
+#else
+#define PT_CONST_AS
+#endif
 
 namespace pt {
 
@@ -88,14 +99,14 @@ struct alignas(16) DTriAttr {
 static_assert(sizeof(DTriAttr) == 80, "DTriAttr must be 80 bytes");
 
 struct DScene {
-    const DObject*   objects;
-    const DMaterial* materials;
-    const DMesh*     meshes;
-    const float*     nodes;      // float4 pairs: {bmin.xyz, skip(int)} {bmax.xyz, tri(int, -1 = interior)}
-    const float*     tris;       // float4 triples: {a.xyz, 0} {e1.xyz, 0} {e2.xyz, 0}
-    const DTriAttr*  triattr;
-    const DTexture*  textures;
-    const uint8_t*   texels;
+    const PT_CONST_AS DObject*   objects;
+    const PT_CONST_AS DMaterial* materials;
+    const PT_CONST_AS DMesh*     meshes;
+    const PT_CONST_AS float*     nodes;      // float4 pairs: {bmin.xyz, skip(int)} {bmax.xyz, tri(int, -1 = interior)}
+    const PT_CONST_AS float*     tris;       // float4 triples: {a.xyz, 0} {e1.xyz, 0} {e2.xyz, 0}
+    const PT_CONST_AS DTriAttr*  triattr;
+    const PT_CONST_AS DTexture*  textures;
+    const PT_CONST_AS uint8_t*   texels;
     int32_t n_objects;
     int32_t n_meshes;
     int32_t n_nodes;
@@ -145,6 +156,7 @@ struct K1Args {
     float*    out;       // [tiles_padded][1024][3]
     uint32_t* sig;       // [tiles_padded][1024] or nullptr
     unsigned long long* diag;   // 8 counters (diagnostic build only) or nullptr
+    float4* park;               // POOLED kernel: parked path records [block][v][q][thread]
 };
 
 }  // namespace pt

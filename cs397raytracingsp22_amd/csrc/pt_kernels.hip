@@ -35,12 +35,16 @@
 
 #pragma clang fp contract(off)
 
+#ifndef PT_MIN_WAVES
+#define PT_MIN_WAVES 4      // waves per SIMD the register allocator must leave room for (<= 128 VGPRs)
+#endif
+
 namespace pt {
 
 // ---------------------------------------------------------------- small vector math
 struct f3 { float x, y, z; };
 __device__ __forceinline__ f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
-__device__ __forceinline__ f3 ld3(const float* p) { return mk3(p[0], p[1], p[2]); }
+template <class FP> __device__ __forceinline__ f3 ld3(FP p) { return mk3(p[0], p[1], p[2]); }   // FP: any float pointer (generic or constant AS)
 __device__ __forceinline__ f3 operator+(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
 __device__ __forceinline__ f3 operator-(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
 __device__ __forceinline__ f3 operator-(f3 a) { return mk3(-a.x, -a.y, -a.z); }
@@ -273,7 +277,7 @@ __device__ __forceinline__ bool slab(f3 bmin, f3 bmax, f3 o, f3 inv_d, float t_m
 }
 
 // Matrix4 (column-major) transforms, cgmath Transform3 (geometry.rs:304,307,297)
-__device__ __forceinline__ f3 xform_point(const float* m, f3 p) {
+template <class FP> __device__ __forceinline__ f3 xform_point(FP m, f3 p) {
     float x = ((m[0] * p.x + m[4] * p.y) + m[8]  * p.z) + m[12] * 1.0f;
     float y = ((m[1] * p.x + m[5] * p.y) + m[9]  * p.z) + m[13] * 1.0f;
     float z = ((m[2] * p.x + m[6] * p.y) + m[10] * p.z) + m[14] * 1.0f;
@@ -281,12 +285,12 @@ __device__ __forceinline__ f3 xform_point(const float* m, f3 p) {
     float iw = 1.0f / w;
     return mk3(x * iw, y * iw, z * iw);
 }
-__device__ __forceinline__ f3 xform_vector(const float* m, f3 v) {
+template <class FP> __device__ __forceinline__ f3 xform_vector(FP m, f3 v) {
     return mk3(((m[0] * v.x + m[4] * v.y) + m[8]  * v.z) + m[12] * 0.0f,
                ((m[1] * v.x + m[5] * v.y) + m[9]  * v.z) + m[13] * 0.0f,
                ((m[2] * v.x + m[6] * v.y) + m[10] * v.z) + m[14] * 0.0f);
 }
-__device__ __forceinline__ f3 xform_vector_transposed(const float* m, f3 v) {
+template <class FP> __device__ __forceinline__ f3 xform_vector_transposed(FP m, f3 v) {
     return mk3(((m[0] * v.x + m[1] * v.y) + m[2]  * v.z) + m[3]  * 0.0f,
                ((m[4] * v.x + m[5] * v.y) + m[6]  * v.z) + m[7]  * 0.0f,
                ((m[8] * v.x + m[9] * v.y) + m[10] * v.z) + m[11] * 0.0f);
@@ -294,27 +298,34 @@ __device__ __forceinline__ f3 xform_vector_transposed(const float* m, f3 v) {
 
 // Texture::sample texture.rs:26-32
 __device__ __forceinline__ f3 tex_sample(const DScene& S, int tex, float u, float v) {
-    DTexture t = S.textures[tex];
-    uint32_t W = (uint32_t)t.width, H = (uint32_t)t.height;
+    const uint32_t t_offset = S.textures[tex].offset;
+    uint32_t W = (uint32_t)S.textures[tex].width, H = (uint32_t)S.textures[tex].height;
     uint32_t x = (uint32_t)(clampf(u, 0.0f, 0.999f) * (float)W);
     if (x > W - 1u) x = W - 1u;
     uint32_t y = (uint32_t)((1.0f - clampf(v, 0.0f, 0.999f)) * (float)H);
     if (y > H - 1u) y = H - 1u;
-    const uint8_t* px = S.texels + t.offset + ((size_t)y * W + x) * 3;
+    auto px = S.texels + t_offset + ((size_t)y * W + x) * 3;
     return mk3((float)px[0] / 255.0f, (float)px[1] / 255.0f, (float)px[2] / 255.0f);
 }
 
 // ---------------------------------------------------------------- BVH storage access
+typedef const PT_CONST_AS float4* cf4_ptr;
+template <bool LDS> struct BvhPtr { typedef cf4_ptr type; };
+template <> struct BvhPtr<true> { typedef const float4* type; };
 template <bool LDS>
 struct Bvh {
-    const float4* nodes;      // global or LDS
-    const float4* tris;
+    typename BvhPtr<LDS>::type nodes;      // LDS, or constant-AS global
+    typename BvhPtr<LDS>::type tris;
     __device__ __forceinline__ void node(int i, float4& n0, float4& n1) const { n0 = nodes[2 * i]; n1 = nodes[2 * i + 1]; }
     __device__ __forceinline__ void tri(int i, f3& a, f3& e1, f3& e2) const {
         float4 t0 = tris[3 * i], t1 = tris[3 * i + 1], t2 = tris[3 * i + 2];
         a = mk3(t0.x, t0.y, t0.z); e1 = mk3(t1.x, t1.y, t1.z); e2 = mk3(t2.x, t2.y, t2.z);
     }
 };
+
+extern __shared__ float4 k1_lds[];
+__device__ __forceinline__ void bvh_bind(Bvh<true>& B, const DScene&, int nn) { B.nodes = k1_lds; B.tris = k1_lds + nn; }
+__device__ __forceinline__ void bvh_bind(Bvh<false>& B, const DScene& S, int) { B.nodes = (cf4_ptr)S.nodes; B.tris = (cf4_ptr)S.tris; }
 
 // BVHNode::intersect_ray (geometry.rs:94-119) as a stackless threaded walk.
 // The recursion passes t_max down unchanged to the left child and the left subtree's
@@ -387,7 +398,7 @@ struct Surf {
 };
 
 __device__ __forceinline__ void load_material(const DScene& S, int id, Surf& s) {
-    const DMaterial* m = &S.materials[id];
+    auto m = &S.materials[id];
     s.kind = m->kind;
     s.albedo = ld3(m->albedo); s.emission = ld3(m->emission);
     s.brdf_diffuse = ld3(m->albedo_over_pi);
@@ -403,14 +414,14 @@ __device__ __forceinline__ void face(f3 normal, f3 dir, f3& n_out, bool& frontfa
 // Build the hit record of the winning object (the reference builds one per candidate
 // and keeps the closest; only the winner's is observable).
 __device__ __forceinline__ void resolve_hit(const DScene& S, const Best& b, f3 o, f3 d, Surf& s) {
-    const DObject* ob = &S.objects[b.obj];
+    auto ob = &S.objects[b.obj];
     int kind = ob->kind;
     if (kind == OBJ_MESH) {
-        const DMesh* M = &S.meshes[ob->ref];
+        auto M = &S.meshes[ob->ref];
         // geometry.rs:304 — object-space ray (direction NOT renormalised)
         f3 oo = xform_point(M->inv_transform, o);
         f3 od = xform_vector(M->inv_transform, d);
-        const DTriAttr* A = &S.triattr[M->tri_begin + b.tri];
+        auto A = &S.triattr[M->tri_begin + b.tri];
         float u = b.u, v = b.v, w = (1.0f - u - v);
         // geometry.rs:351 normalize(u*nb + v*nc + (1-u-v)*na)
         f3 mesh_normal = normalize((ld3(A->nb) * u + ld3(A->nc) * v) + ld3(A->na) * w);
@@ -465,7 +476,8 @@ __device__ __forceinline__ void resolve_hit(const DScene& S, const Best& b, f3 o
 }
 
 // One non-mesh object of Scene.objects against the ray (wave-uniform `ob`).
-__device__ __forceinline__ void test_object(const DObject* ob, int idx, f3 o, f3 d, float t_min, float t_max,
+template <class OP>
+__device__ __forceinline__ void test_object(OP ob, int idx, f3 o, f3 d, float t_min, float t_max,
                                             Rng& rng, Best& best) {
     int kind = ob->kind;
     if (kind == OBJ_TRIANGLE) {
@@ -578,8 +590,6 @@ __device__ __forceinline__ uint32_t sig_end_miss(uint32_t sig, const Rng& r) {
 __device__ __forceinline__ uint32_t sig_end_depth(uint32_t sig) { return lowbias32(sig ^ 0x5bd1e995u); }
 
 // ---------------------------------------------------------------- K1
-extern __shared__ float4 k1_lds[];
-
 template <bool LDS, bool PARK, bool SIG>
 __global__ __launch_bounds__(kBlock) void pt_megakernel(K1Args A) {
     const DScene& S = A.S;
@@ -588,17 +598,14 @@ __global__ __launch_bounds__(kBlock) void pt_megakernel(K1Args A) {
     // ---- stage the mesh BVH into LDS (nodes then triangles) ----
     Bvh<LDS> B;
     if (LDS) {
-        const float4* gn = reinterpret_cast<const float4*>(S.nodes);
-        const float4* gt = reinterpret_cast<const float4*>(S.tris);
+        cf4_ptr gn = (cf4_ptr)S.nodes;
+        cf4_ptr gt = (cf4_ptr)S.tris;
         int nn = (int)A.R.lds_nodes * 2, nt = (int)A.R.lds_tris * 3;
         for (int k = threadIdx.x; k < nn; k += kBlock) k1_lds[k] = gn[k];
         for (int k = threadIdx.x; k < nt; k += kBlock) k1_lds[nn + k] = gt[k];
         __syncthreads();
-        B.nodes = k1_lds; B.tris = k1_lds + nn;
-    } else {
-        B.nodes = reinterpret_cast<const float4*>(S.nodes);
-        B.tris = reinterpret_cast<const float4*>(S.tris);
     }
+    bvh_bind(B, S, (int)A.R.lds_nodes * 2);
 
     // ---- lane -> pixel ----
     const uint32_t slot = blockIdx.x / kBlocksPerTile;            // tile slot of this rank
@@ -661,7 +668,7 @@ __global__ __launch_bounds__(kBlock) void pt_megakernel(K1Args A) {
                 // ---- Scene::intersect_ray over the non-mesh objects, wave-uniform index ----
                 best.obj = -1; best.t = 0.0f; best.tri = -1; best.u = best.v = 0.0f;
                 for (int k = 0; k < S.n_objects; k++) {
-                    const DObject* ob = &S.objects[k];
+                    auto ob = &S.objects[k];
                     if (ob->kind != OBJ_MESH) test_object(ob, k, P.o, P.d, t_min, t_max, P.rng, best);
                 }
                 if (S.n_meshes == 0) resolved = true;
@@ -669,7 +676,7 @@ __global__ __launch_bounds__(kBlock) void pt_megakernel(K1Args A) {
                     // does the ray enter any mesh root box?  (geometry.rs:103 at the root)
                     bool enters = false;
                     for (int m = 0; m < S.n_meshes; m++) {
-                        const DMesh* M = &S.meshes[m];
+                        auto M = &S.meshes[m];
                         f3 oo = xform_point(M->inv_transform, P.o);
                         f3 od = xform_vector(M->inv_transform, P.d);
                         float4 n0, n1;
@@ -688,7 +695,7 @@ __global__ __launch_bounds__(kBlock) void pt_megakernel(K1Args A) {
         if (run_mesh && alive && (PARK ? parked : (!resolved && S.n_meshes > 0))) {
             // ---- StaticMesh::intersect_ray for every mesh (geometry.rs:301-314) ----
             for (int m = 0; m < S.n_meshes; m++) {
-                const DMesh* M = &S.meshes[m];
+                auto M = &S.meshes[m];
                 f3 oo = xform_point(M->inv_transform, P.o);
                 f3 od = xform_vector(M->inv_transform, P.d);
                 float bt, bu, bv; int btri;
@@ -764,7 +771,7 @@ template <class BVH>
 __device__ __forceinline__ bool enter_next_mesh(const DScene& S, const BVH& B, int& m, f3 o, f3 d, float t_min, float t_max,
                                                 f3& oo, f3& od, f3& inv_d, int& ti, int& tend, int& ttb) {
     for (; m < S.n_meshes; m++) {
-        const DMesh* M = &S.meshes[m];
+        auto M = &S.meshes[m];
         oo = xform_point(M->inv_transform, o);                           // geometry.rs:304
         od = xform_vector(M->inv_transform, d);
         inv_d = mk3(1.0f / od.x, 1.0f / od.y, 1.0f / od.z);              // geometry.rs:57
@@ -781,23 +788,20 @@ __device__ __forceinline__ bool enter_next_mesh(const DScene& S, const BVH& B, i
 }
 
 template <bool LDS, bool SIG, bool DIAG>
-__global__ __launch_bounds__(kBlock) void pt_megakernel_voted(K1Args A) {
+__global__ __launch_bounds__(kBlock, PT_MIN_WAVES) void pt_megakernel_voted(K1Args A) {
     const DScene& S = A.S;
     const DCamera& C = A.C;
 
     Bvh<LDS> B;
     if (LDS) {
-        const float4* gn = reinterpret_cast<const float4*>(S.nodes);
-        const float4* gt = reinterpret_cast<const float4*>(S.tris);
+        cf4_ptr gn = (cf4_ptr)S.nodes;
+        cf4_ptr gt = (cf4_ptr)S.tris;
         int nn = (int)A.R.lds_nodes * 2, nt = (int)A.R.lds_tris * 3;
         for (int k = threadIdx.x; k < nn; k += kBlock) k1_lds[k] = gn[k];
         for (int k = threadIdx.x; k < nt; k += kBlock) k1_lds[nn + k] = gt[k];
         __syncthreads();
-        B.nodes = k1_lds; B.tris = k1_lds + nn;
-    } else {
-        B.nodes = reinterpret_cast<const float4*>(S.nodes);
-        B.tris = reinterpret_cast<const float4*>(S.tris);
     }
+    bvh_bind(B, S, (int)A.R.lds_nodes * 2);
 
     const uint32_t slot = blockIdx.x / kBlocksPerTile;
     const uint32_t sub = blockIdx.x % kBlocksPerTile;
@@ -888,7 +892,7 @@ __global__ __launch_bounds__(kBlock) void pt_megakernel_voted(K1Args A) {
                 if (state == ST_A) {
                     best.obj = -1; best.t = 0.0f; best.tri = -1; best.u = best.v = 0.0f;
                     for (int k = 0; k < S.n_objects; k++) {
-                        const DObject* ob = &S.objects[k];
+                        auto ob = &S.objects[k];
                         if (ob->kind != OBJ_MESH) test_object(ob, k, P.o, P.d, t_min, t_max, P.rng, best);
                     }
                     tm = 0;
@@ -947,6 +951,251 @@ __global__ __launch_bounds__(kBlock) void pt_megakernel_voted(K1Args A) {
     if (in_image) { o3[0] = accum.x / n; o3[1] = accum.y / n; o3[2] = accum.z / n; }
     else { o3[0] = 0.0f; o3[1] = 0.0f; o3[2] = 0.0f; }
     if (SIG && A.sig) A.sig[out_idx] = in_image ? sigsum : 0u;
+    if (DIAG && A.diag && lane == 0) {
+        atomicAdd(&A.diag[0], dg_tripsA); atomicAdd(&A.diag[1], dg_lanesA);
+        atomicAdd(&A.diag[2], dg_tripsI); atomicAdd(&A.diag[3], dg_lanesI);
+        atomicAdd(&A.diag[4], dg_tripsL); atomicAdd(&A.diag[5], dg_lanesL);
+        atomicAdd(&A.diag[6], dg_tripsB); atomicAdd(&A.diag[7], 1ull);
+    }
+}
+
+// ---------------------------------------------------------------- K1, pooled (two path slots per lane)
+// The voted kernel's DIAG counters show the limit of one path per lane: lanes in A idle during
+// B trips and lanes in TRAV idle during A trips (A 50 %, interior 30 %, leaf 26 % active).
+// Here every lane owns kV = 2 PIXELS (two path slots): one slot is live in registers, the
+// other is PARKED in a per-lane record in global memory (44 dwords, L2-resident; a lane only
+// ever reads back what it stored itself, so no cross-lane ordering is involved).  A lane whose
+// live path is not in the voted phase swaps to its parked path when that one is, so an A trip
+// runs every lane that has ANY path in A, a B trip every lane with ANY path inside a BVH.
+// A workgroup covers a 32 x 16 half tile (slot v of a lane = rows v*8 .. v*8+7 of it); each
+// pixel is still traced sample by sample by one lane, so results are bit-identical.
+constexpr int kV = 2;
+constexpr int kParkQ = 11;                       // float4 per parked record
+
+struct Slot {            // the part of a path slot that is NOT in `Path`/`Best`
+    f3 accum; uint32_t sigsum, sample;
+    int state; bool fresh, pending;
+    int tm, ti, tend, ttb, tbtri;
+    f3 too, tod, tinv; float tbt, tbu, tbv;
+};
+
+template <bool LDS, bool SIG, bool DIAG>
+__global__ __launch_bounds__(kBlock, PT_MIN_WAVES) void pt_megakernel_pooled(K1Args A) {
+    const DScene& S = A.S;
+    const DCamera& C = A.C;
+
+    Bvh<LDS> B;
+    if (LDS) {
+        cf4_ptr gn = (cf4_ptr)S.nodes;
+        cf4_ptr gt = (cf4_ptr)S.tris;
+        int nn = (int)A.R.lds_nodes * 2, nt = (int)A.R.lds_tris * 3;
+        for (int k = threadIdx.x; k < nn; k += kBlock) k1_lds[k] = gn[k];
+        for (int k = threadIdx.x; k < nt; k += kBlock) k1_lds[nn + k] = gt[k];
+        __syncthreads();
+    }
+    bvh_bind(B, S, (int)A.R.lds_nodes * 2);
+
+    constexpr uint32_t kBlocksPerTileP = kTilePixels / (kBlock * kV);     // 2 half tiles
+    const uint32_t slot = blockIdx.x / kBlocksPerTileP;
+    const uint32_t sub = blockIdx.x % kBlocksPerTileP;
+    const uint32_t tile = slot * (uint32_t)A.R.world + (uint32_t)A.R.rank;
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t in_x = wave * 8 + (lane & 7);
+    const bool tile_ok = tile < A.R.tiles_total;
+    const uint32_t px = tile_ok ? (tile % A.R.tiles_x) * kTile + in_x : 0u;
+    const uint32_t tile_y0 = tile_ok ? (tile / A.R.tiles_x) * kTile : 0u;
+    const float t_min = 0.001f, t_max = C.max_trace_dist;
+    const int vote_t = (int)A.R.vote_t, vote_a = (int)A.R.vote_a, k_steps = (int)A.R.k_steps;
+
+    // this lane's park records: [block][v][q][thread] float4 (coalesced per q)
+    float4* park = A.park + ((size_t)blockIdx.x * kV * kParkQ) * kBlock + threadIdx.x;
+
+    enum : int { ST_A = 0, ST_TRAV = 1, ST_DEAD = 2 };
+
+    // per-slot pixel identity, recomputed whenever the live slot changes
+    int cur = 0;
+    uint32_t in_y, py, pixel, out_idx, spp;
+    auto bind_pixel = [&](int v) {
+        in_y = sub * (8 * kV) + (uint32_t)v * 8 + (lane >> 3);
+        py = tile_y0 + in_y;
+        pixel = py * C.width + px;
+        out_idx = slot * kTilePixels + in_y * kTile + in_x;
+        spp = (tile_ok && px < C.width && py < C.height) ? C.spp : 0u;
+    };
+    bind_pixel(0);
+
+    Path P;
+    P.o = P.d = P.T = P.L = mk3(0.0f, 0.0f, 0.0f); P.depth = 0; P.sig = 0; P.rng.s0 = P.rng.s1 = 1u;
+    Best best; best.t = 0.0f; best.obj = -1; best.tri = -1; best.u = best.v = 0.0f;
+    Slot Q;
+    Q.accum = mk3(0.0f, 0.0f, 0.0f); Q.sigsum = 0; Q.sample = 0; Q.state = ST_A; Q.fresh = true; Q.pending = false;
+    Q.tm = Q.ti = Q.tend = Q.ttb = 0; Q.tbtri = -1;
+    Q.too = Q.tod = Q.tinv = mk3(0.0f, 0.0f, 0.0f); Q.tbt = Q.tbu = Q.tbv = 0.0f;
+    int pstate = ST_A;                                   // state of the parked slot (kept in a register for the votes)
+
+    // the parked slot starts as an untouched pixel: all zero, flags = A | fresh
+    {
+        float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        float4* rec = park + (size_t)1 * kParkQ * kBlock;
+#pragma unroll
+        for (int q = 0; q < kParkQ - 1; q++) rec[(size_t)q * kBlock] = z;
+        rec[(size_t)(kParkQ - 1) * kBlock] = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(ST_A | 4));
+    }
+
+    unsigned long long dg_tripsA = 0, dg_lanesA = 0, dg_tripsI = 0, dg_lanesI = 0, dg_tripsL = 0, dg_lanesL = 0, dg_tripsB = 0;
+
+    while (true) {
+        const int nA = __popcll(__ballot(Q.state == ST_A || pstate == ST_A));
+        const int nT = __popcll(__ballot(Q.state == ST_TRAV || pstate == ST_TRAV));
+        if (nA + nT == 0) break;
+        const bool run_b = (nT > 0) && (nT * vote_t >= nA * vote_a);
+        const int want = run_b ? ST_TRAV : ST_A;
+
+        // ---- swap the live path with the parked one when only the parked one is in the voted phase ----
+        if (Q.state != want && pstate == want) {
+            float4* mine = park + (size_t)cur * kParkQ * kBlock;
+            float4* other = park + (size_t)(1 - cur) * kParkQ * kBlock;
+            float4 r0 = other[0 * kBlock], r1 = other[1 * kBlock], r2 = other[2 * kBlock], r3 = other[3 * kBlock];
+            float4 r4 = other[4 * kBlock], r5 = other[5 * kBlock], r6 = other[6 * kBlock], r7 = other[7 * kBlock];
+            float4 r8 = other[8 * kBlock], r9 = other[9 * kBlock], r10 = other[10 * kBlock];
+            if (Q.state != ST_DEAD) {
+                mine[0 * kBlock] = make_float4(P.o.x, P.o.y, P.o.z, P.d.x);
+                mine[1 * kBlock] = make_float4(P.d.y, P.d.z, P.T.x, P.T.y);
+                mine[2 * kBlock] = make_float4(P.T.z, P.L.x, P.L.y, P.L.z);
+                mine[3 * kBlock] = make_float4(Q.accum.x, Q.accum.y, Q.accum.z, __uint_as_float(P.rng.s0));
+                mine[4 * kBlock] = make_float4(__uint_as_float(P.rng.s1), __uint_as_float(Q.sample), __uint_as_float(P.depth), __uint_as_float(P.sig));
+                mine[5 * kBlock] = make_float4(__uint_as_float(Q.sigsum), best.t, __int_as_float(best.obj), __int_as_float(best.tri));
+                mine[6 * kBlock] = make_float4(best.u, best.v, Q.tbt, __int_as_float(Q.tbtri));
+                mine[7 * kBlock] = make_float4(Q.tbu, Q.tbv, __int_as_float(Q.ti), __int_as_float(Q.tm));
+                mine[8 * kBlock] = make_float4(Q.too.x, Q.too.y, Q.too.z, Q.tod.x);
+                mine[9 * kBlock] = make_float4(Q.tod.y, Q.tod.z, Q.tinv.x, Q.tinv.y);
+                mine[10 * kBlock] = make_float4(Q.tinv.z, __int_as_float(Q.tend), __int_as_float(Q.ttb),
+                                                __int_as_float(Q.state | (Q.fresh ? 4 : 0) | (Q.pending ? 8 : 0)));
+            }
+            const int old_state = Q.state;
+            P.o = mk3(r0.x, r0.y, r0.z); P.d = mk3(r0.w, r1.x, r1.y); P.T = mk3(r1.z, r1.w, r2.x); P.L = mk3(r2.y, r2.z, r2.w);
+            Q.accum = mk3(r3.x, r3.y, r3.z); P.rng.s0 = __float_as_uint(r3.w);
+            P.rng.s1 = __float_as_uint(r4.x); Q.sample = __float_as_uint(r4.y); P.depth = __float_as_uint(r4.z); P.sig = __float_as_uint(r4.w);
+            Q.sigsum = __float_as_uint(r5.x); best.t = r5.y; best.obj = __float_as_int(r5.z); best.tri = __float_as_int(r5.w);
+            best.u = r6.x; best.v = r6.y; Q.tbt = r6.z; Q.tbtri = __float_as_int(r6.w);
+            Q.tbu = r7.x; Q.tbv = r7.y; Q.ti = __float_as_int(r7.z); Q.tm = __float_as_int(r7.w);
+            Q.too = mk3(r8.x, r8.y, r8.z); Q.tod = mk3(r8.w, r9.x, r9.y); Q.tinv = mk3(r9.z, r9.w, r10.x);
+            Q.tend = __float_as_int(r10.y); Q.ttb = __float_as_int(r10.z);
+            const int fl = __float_as_int(r10.w);
+            Q.state = fl & 3; Q.fresh = (fl & 4) != 0; Q.pending = (fl & 8) != 0;
+            pstate = old_state;
+            cur = 1 - cur;
+            bind_pixel(cur);
+        }
+
+        if (!run_b) {
+            if (DIAG) { dg_tripsA++; dg_lanesA += (unsigned long long)__popcll(__ballot(Q.state == ST_A)); }
+            if (Q.state == ST_A) {
+                // ---- (a) Scene::shade_ray, one level, for the intersection found earlier ----
+                if (Q.pending) {
+                    Q.pending = false;
+                    bool end_path;
+                    if (best.obj < 0) {
+                        end_path = true;
+                        if (SIG) P.sig = sig_end_miss(P.sig, P.rng);
+                    } else {
+                        if (SIG) P.sig = sig_hit(P.sig, best.t, best.obj);
+                        Surf s;
+                        resolve_hit(S, best, P.o, P.d, s);
+                        P.L = mk3(P.L.x + P.T.x * s.emission.x, P.L.y + P.T.y * s.emission.y, P.L.z + P.T.z * s.emission.z);
+                        P.depth++;
+                        if (P.depth >= C.path_depth) {
+                            end_path = true;
+                            if (SIG) P.sig = sig_end_depth(P.sig);
+                        } else {
+                            f3 nd, w;
+                            scatter(s, P.d, P.rng, nd, w);
+                            P.o = s.p; P.d = nd;
+                            P.T = mk3(P.T.x * w.x, P.T.y * w.y, P.T.z * w.z);
+                            end_path = false;
+                        }
+                    }
+                    if (end_path) {
+                        Q.accum = Q.accum + P.L;
+                        if (SIG) Q.sigsum += P.sig;
+                        Q.sample++;
+                        Q.fresh = true;
+                    }
+                }
+                // ---- (b) Camera::generate_rays for the next sample, or retire the pixel ----
+                if (Q.fresh) {
+                    if (Q.sample >= spp) {
+                        // per-pixel mean (tracing.rs:241); pixels outside the image are written as 0
+                        float n = (float)C.spp;
+                        float* o3 = A.out + (size_t)out_idx * 3;
+                        if (spp != 0u) { o3[0] = Q.accum.x / n; o3[1] = Q.accum.y / n; o3[2] = Q.accum.z / n; }
+                        else { o3[0] = 0.0f; o3[1] = 0.0f; o3[2] = 0.0f; }
+                        if (SIG && A.sig) A.sig[out_idx] = spp != 0u ? Q.sigsum : 0u;
+                        Q.state = ST_DEAD;
+                    } else {
+                        rng_init(P.rng, A.seed_key, pixel, Q.sample);
+                        generate_ray(C, px, py, Q.sample, P.rng, P.o, P.d);
+                        P.T = mk3(1.0f, 1.0f, 1.0f); P.L = mk3(0.0f, 0.0f, 0.0f); P.depth = 0; P.sig = 0;
+                        Q.fresh = false;
+                    }
+                }
+                // ---- (c) Scene::intersect_ray: the object list, then the mesh roots ----
+                if (Q.state == ST_A) {
+                    best.obj = -1; best.t = 0.0f; best.tri = -1; best.u = best.v = 0.0f;
+                    for (int k = 0; k < S.n_objects; k++) {
+                        auto ob = &S.objects[k];
+                        if (ob->kind != OBJ_MESH) test_object(ob, k, P.o, P.d, t_min, t_max, P.rng, best);
+                    }
+                    Q.tm = 0;
+                    if (enter_next_mesh(S, B, Q.tm, P.o, P.d, t_min, t_max, Q.too, Q.tod, Q.tinv, Q.ti, Q.tend, Q.ttb)) {
+                        Q.state = ST_TRAV; Q.tbt = t_max; Q.tbtri = -1; Q.tbu = Q.tbv = 0.0f;
+                    } else {
+                        Q.pending = true;
+                    }
+                }
+            }
+        } else {
+            if (DIAG) dg_tripsB++;
+            // ---- B-trip: BVHNode::intersect_ray (geometry.rs:94-119), k_steps voted micro-steps ----
+            for (int k = 0; k < k_steps; k++) {
+                const bool in_t = (Q.state == ST_TRAV);
+                float4 n0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), n1 = n0;
+                int tri = -1;
+                if (in_t) { B.node(Q.ti, n0, n1); tri = __float_as_int(n1.w); }
+                const bool at_leaf = in_t && tri >= 0, at_inner = in_t && tri < 0;
+                const int n_leaf = __popcll(__ballot(at_leaf)), n_inner = __popcll(__ballot(at_inner));
+                if (n_leaf + n_inner == 0) break;
+                if (n_inner >= n_leaf) {
+                    if (DIAG) { dg_tripsI++; dg_lanesI += (unsigned long long)n_inner; }
+                    if (at_inner) {
+                        bool hit = slab(mk3(n0.x, n0.y, n0.z), mk3(n1.x, n1.y, n1.z), Q.too, Q.tinv, t_min, Q.tbt);   // :103
+                        Q.ti = hit ? Q.ti + 1 : __float_as_int(n0.w);
+                    }
+                } else {
+                    if (DIAG) { dg_tripsL++; dg_lanesL += (unsigned long long)n_leaf; }
+                    if (at_leaf) {
+                        f3 a, e1, e2;
+                        B.tri(Q.ttb + tri, a, e1, e2);
+                        float t, u, v;
+                        if (tri_t(Q.too, Q.tod, a, e1, e2, t_min, Q.tbt, t, u, v)) {                                  // :97
+                            Q.tbt = t; Q.tbtri = tri; Q.tbu = u; Q.tbv = v;
+                        }
+                        Q.ti = Q.ti + 1;
+                    }
+                }
+                if (in_t && Q.ti >= Q.tend) {
+                    if (Q.tbtri >= 0) consider(best, Q.tbt, S.meshes[Q.tm].object_index, Q.tbtri, Q.tbu, Q.tbv);
+                    Q.tm++;
+                    if (enter_next_mesh(S, B, Q.tm, P.o, P.d, t_min, t_max, Q.too, Q.tod, Q.tinv, Q.ti, Q.tend, Q.ttb)) {
+                        Q.tbt = t_max; Q.tbtri = -1; Q.tbu = Q.tbv = 0.0f;
+                    } else {
+                        Q.state = ST_A; Q.pending = true;
+                    }
+                }
+            }
+        }
+    }
+
     if (DIAG && A.diag && lane == 0) {
         atomicAdd(&A.diag[0], dg_tripsA); atomicAdd(&A.diag[1], dg_lanesA);
         atomicAdd(&A.diag[2], dg_tripsI); atomicAdd(&A.diag[3], dg_lanesI);
@@ -1028,6 +1277,20 @@ hipError_t launch_megakernel_voted(const K1Args& args, uint32_t n_blocks, bool l
     else          { if (sig) PT_LAUNCH_V(false, true, false); else PT_LAUNCH_V(false, false, false); }
 #undef PT_LAUNCH_V
     return hipGetLastError();
+}
+
+hipError_t launch_megakernel_pooled(const K1Args& args, uint32_t tiles_padded, bool lds, bool sig, bool diag,
+                                    size_t lds_bytes, hipStream_t stream) {
+    dim3 grid(tiles_padded * (uint32_t)(kTilePixels / (kBlock * kV))), block(kBlock);
+#define PT_LAUNCH_P(L, G, D) hipLaunchKernelGGL((pt_megakernel_pooled<L, G, D>), grid, block, (L) ? lds_bytes : 0, stream, args)
+    if (diag) { if (lds) PT_LAUNCH_P(true, true, true); else PT_LAUNCH_P(false, true, true); }
+    else if (lds) { if (sig) PT_LAUNCH_P(true, true, false); else PT_LAUNCH_P(true, false, false); }
+    else          { if (sig) PT_LAUNCH_P(false, true, false); else PT_LAUNCH_P(false, false, false); }
+#undef PT_LAUNCH_P
+    return hipGetLastError();
+}
+size_t pooled_park_bytes(uint32_t tiles_padded) {
+    return (size_t)tiles_padded * (size_t)(kTilePixels / (kBlock * kV)) * kV * kParkQ * kBlock * sizeof(float4);
 }
 
 hipError_t launch_unpermute(const float* gathered, float* image, uint32_t width, uint32_t height, uint32_t tiles_x,

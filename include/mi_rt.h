@@ -179,7 +179,9 @@ typedef enum mi_variant {
     MI_VARIANT_SIMPLE     = 1,  /* one segment per loop trip, mesh traversal in line               */
     MI_VARIANT_PARKED     = 2,  /* mesh rays parked, traversed together when a __ballot vote says so */
     MI_VARIANT_VOTED      = 3,  /* per-lane state machine; every BVH node step is a __ballot-voted phase */
-    MI_VARIANT_VOTED_DIAG = 4   /* VOTED + per-phase trip / active-lane counters (never timed)      */
+    MI_VARIANT_VOTED_DIAG = 4,  /* VOTED + per-phase trip / active-lane counters (never timed)      */
+    MI_VARIANT_POOLED     = 5,  /* VOTED with two path slots per lane (one parked in L2); experimental, slower */
+    MI_VARIANT_POOLED_DIAG = 6  /* POOLED + counters (never timed)                                  */
 } mi_variant;
 
 typedef struct mi_stats {
@@ -234,7 +236,7 @@ int  mi_tonemap_device(mi_ctx* ctx, const mi_camera_desc* cam,
  * launch stream); synchronises on the stop event. */
 int  mi_last_kernel_ms(mi_ctx* ctx, float* ms);
 
-/* Counters of the most recent MI_VARIANT_VOTED_DIAG launch (synchronises the device):
+/* Counters of the most recent *_DIAG launch (synchronises the device):
  * out8 = { A trips, sum of lanes in A trips, interior-step trips, lanes, leaf-step trips,
  *          lanes, B trips, waves }.  active-lane fraction of a phase = lanes / (64 * trips). */
 int  mi_last_diag(mi_ctx* ctx, uint64_t* out8);

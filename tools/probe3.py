@@ -10,15 +10,16 @@ sc = {"cfg2": lambda: scenes.config2(1920, 1080, spp, 10), "cfg1": lambda: scene
       "head": lambda: scenes.head_scene(1920, 1080, spp, 10, textures=scenes.load_asset_textures())}[which]()
 ctx = Context(0)
 ctx.upload(sc.flatten())
-for vname, v in (("simple", 1), ("parked", 2), ("voted", 3)):
+for vname, v in (("simple", 1), ("parked", 2), ("voted", 3), ("pooled", 5)):
     best = 1e30
     for rep in range(2):
         _, _, _, st = ctx.render(sc.camera, seed=1, want_f32=True, want_u8=False, variant=v)
         best = min(best, st.kernel_ms)
     print(f"{which} {vname}: kernel_ms={best:.2f} Msamples/s={st.samples / best / 1e3:.1f}", flush=True)
-ctx.render(sc.camera, seed=1, want_f32=True, want_u8=False, variant=4)
-d = ctx.last_diag()
-print(d)
-for k in ("a", "inner", "leaf"):
-    t, l = d[k + "_trips"], d[k + "_lanes"]
-    print(f"  {k}: trips/wave={t / max(1, d['waves']):.0f} active-lane fraction={l / max(1, 64 * t):.3f}")
+for dv in (4, 6):
+    ctx.render(sc.camera, seed=1, want_f32=True, want_u8=False, variant=dv)
+    d = ctx.last_diag()
+    print("diag variant", dv, d)
+    for k in ("a", "inner", "leaf"):
+        t, l = d[k + "_trips"], d[k + "_lanes"]
+        print(f"  {k}: trips/wave={t / max(1, d['waves']):.0f} active-lane fraction={l / max(1, 64 * t):.3f}")
