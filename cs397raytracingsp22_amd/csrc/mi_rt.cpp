@@ -303,6 +303,7 @@ extern "C" int mi_scene_upload(mi_ctx* c, const mi_scene_desc* d) {
         DObject& D = objs[(size_t)i];
         memset(&D, 0, sizeof D);
         D.kind = o.kind;
+        D.index = i;
         switch (o.kind) {
         case MI_OBJ_SPHERE: {
             if (o.index < 0 || o.index >= d->n_spheres || !d->spheres) return fail(MI_ERR_INVALID, "object %d: bad sphere index", i);
@@ -361,10 +362,20 @@ extern "C" int mi_scene_upload(mi_ctx* c, const mi_scene_desc* d) {
     for (int i = 0; i < d->n_objects; i++)
         if (objs[(size_t)i].kind == OBJ_MESH) { int r = objs[(size_t)i].ref; objs[(size_t)i].ref = (int)live.size(); live.push_back(meshes[(size_t)r]); }
 
-    // one blob: objects | materials | meshes | nodes | tris | attrs | textures | texels
+    // kind-grouped copy of the non-mesh objects (stable within a kind)
+    std::vector<DObject> list;
+    int n_list[4] = { 0, 0, 0, 0 };
+    {
+        const int order[4] = { OBJ_TRIANGLE, OBJ_SPHERE, OBJ_PLANE, OBJ_VOLUME };
+        for (int g = 0; g < 4; g++)
+            for (size_t i = 0; i < objs.size(); i++)
+                if (objs[i].kind == order[g]) { list.push_back(objs[i]); n_list[g]++; }
+    }
+    // one blob: objects | list | materials | meshes | nodes | tris | attrs | textures | texels
     auto align = [](size_t x) { return (x + 255) & ~(size_t)255; };
     size_t off_obj = 0;
-    size_t off_mat = align(off_obj + objs.size() * sizeof(DObject));
+    size_t off_list = align(off_obj + objs.size() * sizeof(DObject));
+    size_t off_mat = align(off_list + (list.size() + 1) * sizeof(DObject));      // +1: the loop prefetches one record ahead
     size_t off_mesh = align(off_mat + mats.size() * sizeof(DMaterial));
     size_t off_nodes = align(off_mesh + live.size() * sizeof(DMesh));
     size_t off_tris = align(off_nodes + nodes.size() * 4);
@@ -376,6 +387,7 @@ extern "C" int mi_scene_upload(mi_ctx* c, const mi_scene_desc* d) {
     std::vector<uint8_t> host(total, 0);
     auto put = [&](size_t off, const void* p, size_t n) { if (n) memcpy(host.data() + off, p, n); };
     put(off_obj, objs.data(), objs.size() * sizeof(DObject));
+    put(off_list, list.data(), list.size() * sizeof(DObject));
     put(off_mat, mats.data(), mats.size() * sizeof(DMaterial));
     put(off_mesh, live.data(), live.size() * sizeof(DMesh));
     put(off_nodes, nodes.data(), nodes.size() * 4);
@@ -391,6 +403,8 @@ extern "C" int mi_scene_upload(mi_ctx* c, const mi_scene_desc* d) {
     HIP_TRY(hipMemcpy(c->blob, host.data(), total, hipMemcpyHostToDevice));
     uint8_t* b = (uint8_t*)c->blob;
     c->S.objects = (const DObject*)(b + off_obj);
+    c->S.list = (const DObject*)(b + off_list);
+    c->S.n_list_tri = n_list[0]; c->S.n_list_sphere = n_list[1]; c->S.n_list_plane = n_list[2]; c->S.n_list_volume = n_list[3];
     c->S.materials = (const DMaterial*)(b + off_mat);
     c->S.meshes = (const DMesh*)(b + off_mesh);
     c->S.nodes = (const float*)(b + off_nodes);

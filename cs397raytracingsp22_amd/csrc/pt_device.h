@@ -49,7 +49,7 @@ struct alignas(16) DObject {
     int32_t kind;
     int32_t material;    // material index (phase function for VOLUME); unused for MESH
     int32_t ref;         // mesh index for MESH
-    int32_t pad;
+    int32_t index;       // position in Scene.objects (used by the kind-grouped `list` copy)
     float   f[12];
 };
 static_assert(sizeof(DObject) == 64, "DObject must be 64 bytes");
@@ -107,6 +107,13 @@ struct DScene {
     const PT_CONST_AS DTriAttr*  triattr;
     const PT_CONST_AS DTexture*  textures;
     const PT_CONST_AS uint8_t*   texels;
+    // the non-mesh objects again, GROUPED BY KIND (triangles, spheres, planes, volumes; stable
+    // within a kind), each record carrying its Scene.objects index: the hit loop runs one
+    // tight loop per kind with no per-object dispatch.  Exact: the closest hit is order
+    // independent, ties go to the lower Scene.objects index (tracing.rs:335), and only
+    // volumes draw random numbers, in their original relative order (geometry.rs:517).
+    const PT_CONST_AS DObject*   list;
+    int32_t n_list_tri, n_list_sphere, n_list_plane, n_list_volume;
     int32_t n_objects;
     int32_t n_meshes;
     int32_t n_nodes;

@@ -215,6 +215,12 @@ __device__ __forceinline__ f3 rotate_from_unit_y(f3 n, f3 dir) {
 }
 
 // ---------------------------------------------------------------- primitive tests
+// The primitive tests are written WITHOUT early returns: in a 64-wide wave an early return
+// only saves work when all lanes take it (they almost never do), but every `if (..) return`
+// costs a v_cmp + s_and_saveexec + s_cbranch + s_or pair on the scalar unit, and a wave issues
+// one instruction at a time.  Each reject condition is the reference's, combined with `|`
+// (NaN behaviour preserved: a comparison with NaN is false, as in the Rust source).
+
 // Sphere::intersect_ray geometry.rs:395-413 -> parametric t, or miss
 __device__ __forceinline__ bool sphere_t(f3 o, f3 d, f3 center, float r2, float t_min, float t_max, float& t_out) {
     f3 f = o - center;
@@ -222,14 +228,12 @@ __device__ __forceinline__ bool sphere_t(f3 o, f3 d, f3 center, float r2, float 
     float b = 2.0f * dot(f, d);
     float c = mag2(f) - r2;
     float disc = b * b - 4.0f * a * c;
-    if (disc < 0.0f) return false;
-    float sq = sqrtf(disc);
+    float sq = sqrtf(disc);                       // NaN when disc < 0: that lane is rejected below
     float t1 = (-b - sq) / (2.0f * a);
     float t2 = (-b + sq) / (2.0f * a);
     float t = (t1 >= t_min) ? t1 : t2;
-    if (t < t_min || t > t_max) return false;
     t_out = t;
-    return true;
+    return !((disc < 0.0f) | (t < t_min) | (t > t_max));
 }
 
 // Triangle / IndexedTriangle Moller-Trumbore geometry.rs:331-349, 431-447
@@ -237,43 +241,43 @@ __device__ __forceinline__ bool tri_t(f3 o, f3 d, f3 a, f3 e1, f3 e2, float t_mi
                                       float& t_out, float& u_out, float& v_out) {
     f3 q = cross(d, e2);
     float g = dot(e1, q);
-    if (fabsf(g) < 0.0001f) return false;
     float f = 1.0f / g;
     f3 s = o - a;
     float u = f * dot(s, q);
-    if (u < 0.0f) return false;
     f3 r = cross(s, e1);
     float v = f * dot(d, r);
-    if (v < 0.0f || u + v > 1.0f) return false;
     float t = f * dot(e2, r);
-    if (t < t_min || t > t_max) return false;
     t_out = t; u_out = u; v_out = v;
-    return true;
+    return !((fabsf(g) < 0.0001f) | (u < 0.0f) | (v < 0.0f) | (u + v > 1.0f) | (t < t_min) | (t > t_max));
 }
 
 // AABB::intersect_ray geometry.rs:52-79 with 1/d hoisted out of the node loop (the
 // reference recomputes the same 1/d at every box).
 __device__ __forceinline__ bool slab(f3 bmin, f3 bmax, f3 o, f3 inv_d, float t_min, float t_max) {
     float tmin = t_min, tmax = t_max;
+    bool rej;
     {
         float t0 = (bmin.x - o.x) * inv_d.x, t1 = (bmax.x - o.x) * inv_d.x;
-        if (inv_d.x < 0.0f) { float t = t0; t0 = t1; t1 = t; }
-        tmin = fmaxf(t0, tmin); tmax = fminf(t1, tmax);
-        if (tmax <= tmin) return false;
+        bool sw = inv_d.x < 0.0f;
+        float ta = sw ? t1 : t0, tb = sw ? t0 : t1;
+        tmin = fmaxf(ta, tmin); tmax = fminf(tb, tmax);
+        rej = (tmax <= tmin);
     }
     {
         float t0 = (bmin.y - o.y) * inv_d.y, t1 = (bmax.y - o.y) * inv_d.y;
-        if (inv_d.y < 0.0f) { float t = t0; t0 = t1; t1 = t; }
-        tmin = fmaxf(t0, tmin); tmax = fminf(t1, tmax);
-        if (tmax <= tmin) return false;
+        bool sw = inv_d.y < 0.0f;
+        float ta = sw ? t1 : t0, tb = sw ? t0 : t1;
+        tmin = fmaxf(ta, tmin); tmax = fminf(tb, tmax);
+        rej = rej | (tmax <= tmin);
     }
     {
         float t0 = (bmin.z - o.z) * inv_d.z, t1 = (bmax.z - o.z) * inv_d.z;
-        if (inv_d.z < 0.0f) { float t = t0; t0 = t1; t1 = t; }
-        tmin = fmaxf(t0, tmin); tmax = fminf(t1, tmax);
-        if (tmax <= tmin) return false;
+        bool sw = inv_d.z < 0.0f;
+        float ta = sw ? t1 : t0, tb = sw ? t0 : t1;
+        tmin = fmaxf(ta, tmin); tmax = fminf(tb, tmax);
+        rej = rej | (tmax <= tmin);
     }
-    return true;
+    return !rej;
 }
 
 // Matrix4 (column-major) transforms, cgmath Transform3 (geometry.rs:304,307,297)
@@ -512,6 +516,52 @@ __device__ __forceinline__ void test_object(OP ob, int idx, f3 o, f3 d, float t_
                 if (dist_before_scatter < dist_in_volume)
                     consider(best, t_start + dist_before_scatter, idx, -1, 0.0f, 0.0f);
             }
+        }
+    }
+}
+
+// Scene::intersect_ray over the non-mesh objects (tracing.rs:330-344) through the
+// kind-grouped list: one tight loop per kind, the record of the next object loaded (scalar
+// load, wave-uniform address) while the current one is tested.
+__device__ __forceinline__ void consider_list(Best& b, bool ok, float t, int obj) {
+    bool take = ok & ((b.obj < 0) | (t < b.t) | ((t == b.t) & (obj < b.obj)));
+    b.t = take ? t : b.t;
+    b.obj = take ? obj : b.obj;
+}
+__device__ __forceinline__ void intersect_list(const DScene& S, f3 o, f3 d, float t_min, float t_max, Rng& rng, Best& best) {
+    auto L = S.list;
+    int k = 0;
+    {   // Triangle::intersect_ray geometry.rs:431-450
+        const int end = S.n_list_tri;
+        float c[12]; int ci = L[k].index;
+#pragma unroll
+        for (int j = 0; j < 12; j++) c[j] = L[k].f[j];
+        for (; k < end; k++) {
+            float n[12]; int ni = L[k + 1].index;            // one record of slack is allocated past the end
+#pragma unroll
+            for (int j = 0; j < 12; j++) n[j] = L[k + 1].f[j];
+            float t, u, v;
+            bool ok = tri_t(o, d, mk3(c[0], c[1], c[2]), mk3(c[3], c[4], c[5]), mk3(c[6], c[7], c[8]), t_min, t_max, t, u, v);
+            consider_list(best, ok, t, ci);
+            ci = ni;
+#pragma unroll
+            for (int j = 0; j < 12; j++) c[j] = n[j];
+        }
+    }
+    {   // Sphere::intersect_ray geometry.rs:395-413
+        const int end = k + S.n_list_sphere;
+        for (; k < end; k++) {
+            auto ob = &L[k];
+            float t;
+            bool ok = sphere_t(o, d, ld3(ob->f), ob->f[4], t_min, t_max, t);
+            consider_list(best, ok, t, ob->index);
+        }
+    }
+    {   // Plane (geometry.rs:474-489) and ConvexVolume (geometry.rs:502-526): rare kinds, generic code
+        const int end = k + S.n_list_plane + S.n_list_volume;
+        for (; k < end; k++) {
+            auto ob = &L[k];
+            test_object(ob, ob->index, o, d, t_min, t_max, rng, best);
         }
     }
 }
@@ -891,10 +941,7 @@ __global__ __launch_bounds__(kBlock, PT_MIN_WAVES) void pt_megakernel_voted(K1Ar
                 // ---- (c) Scene::intersect_ray: the object list, then the mesh roots ----
                 if (state == ST_A) {
                     best.obj = -1; best.t = 0.0f; best.tri = -1; best.u = best.v = 0.0f;
-                    for (int k = 0; k < S.n_objects; k++) {
-                        auto ob = &S.objects[k];
-                        if (ob->kind != OBJ_MESH) test_object(ob, k, P.o, P.d, t_min, t_max, P.rng, best);
-                    }
+                    intersect_list(S, P.o, P.d, t_min, t_max, P.rng, best);
                     tm = 0;
                     if (enter_next_mesh(S, B, tm, P.o, P.d, t_min, t_max, too, tod, tinv, ti, tend, ttb)) {
                         state = ST_TRAV; tbt = t_max; tbtri = -1; tbu = tbv = 0.0f;
@@ -1142,10 +1189,7 @@ __global__ __launch_bounds__(kBlock, PT_MIN_WAVES) void pt_megakernel_pooled(K1A
                 // ---- (c) Scene::intersect_ray: the object list, then the mesh roots ----
                 if (Q.state == ST_A) {
                     best.obj = -1; best.t = 0.0f; best.tri = -1; best.u = best.v = 0.0f;
-                    for (int k = 0; k < S.n_objects; k++) {
-                        auto ob = &S.objects[k];
-                        if (ob->kind != OBJ_MESH) test_object(ob, k, P.o, P.d, t_min, t_max, P.rng, best);
-                    }
+                    intersect_list(S, P.o, P.d, t_min, t_max, P.rng, best);
                     Q.tm = 0;
                     if (enter_next_mesh(S, B, Q.tm, P.o, P.d, t_min, t_max, Q.too, Q.tod, Q.tinv, Q.ti, Q.tend, Q.ttb)) {
                         Q.state = ST_TRAV; Q.tbt = t_max; Q.tbtri = -1; Q.tbu = Q.tbv = 0.0f;
