@@ -125,6 +125,13 @@ def load() -> C.CDLL:
             f"{LIB_PATH} is missing: the HIP library has not been built "
             "(run `python -c 'import __graft_entry__ as g; g.build()'`). "
             "There is no CPU fallback for the render path.")
+    # If the process also uses torch (device tensors, torch.distributed), torch's bundled HIP
+    # runtime must be the one in the process: load it before libmi_rt.so resolves libamdhip64.
+    import sys
+    if "torch" in sys.modules or os.environ.get("MI_RT_PRELOAD_TORCH") == "1":
+        import torch  # noqa: F401
+        if torch.cuda.is_available():
+            torch.cuda.init()
     lib = C.CDLL(LIB_PATH)
     vp = C.c_void_p
     lib.mi_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]

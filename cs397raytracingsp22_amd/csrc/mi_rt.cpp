@@ -490,7 +490,7 @@ static int render_tiles(mi_ctx* c, const mi_camera_desc* cam, const mi_render_op
     a.R.seed = o->seed; a.R.rank = o->rank; a.R.world = o->world;
     a.R.tiles_x = tx; a.R.tiles_y = ty; a.R.tiles_total = total;
     a.R.my_tiles = (total > (uint32_t)o->rank) ? (total - (uint32_t)o->rank + (uint32_t)o->world - 1) / (uint32_t)o->world : 0;
-    bool lds = c->S.n_meshes > 0 && c->lds_bytes <= 64u * 1024u;
+    bool lds = c->S.n_meshes > 0 && c->lds_bytes <= 64u * 1024u && !getenv("MI_RT_GLOBAL_BVH");   // env: developer experiment
     a.R.lds_nodes = lds ? (uint32_t)c->S.n_nodes : 0;
     a.R.lds_tris = lds ? (uint32_t)c->S.n_tris : 0;
     a.seed_key = lowbias32(o->seed ^ 0x68e31da4u);

@@ -73,6 +73,9 @@ class TiledRenderer:
     def __init__(self, ctx, camera, rank: int = 0, world: int = 1, device: Optional[str] = None,
                  variant: int = abi.MI_VARIANT_DEFAULT):
         import torch
+        if not torch.cuda.is_available():
+            raise RuntimeError("torch cannot see the GPU: import torch BEFORE creating a Context "
+                               "(its bundled HIP runtime must be the first one loaded into the process)")
         self.torch = torch
         self.ctx, self.cam, self.rank, self.world, self.variant = ctx, camera, rank, world, variant
         self.device = torch.device(device if device is not None else f"cuda:{ctx.device}")

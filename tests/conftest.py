@@ -3,6 +3,11 @@ import sys
 
 import pytest
 
+# torch bundles its own HIP runtime (libamdhip64).  It has to be the FIRST HIP runtime loaded
+# into the process: if libmi_rt.so pulls in /opt/rocm's copy first, torch.cuda later reports
+# "No HIP GPUs are available".  bench.py imports torch first for the same reason.
+import torch  # noqa: F401,E402
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
