@@ -96,6 +96,7 @@ struct mi_ctx {
     unsigned long long* d_diag = nullptr;    // 8 counters of the diagnostic variant
     void* d_park = nullptr; size_t park_bytes = 0;   // parked path records of the POOLED kernel
     uint32_t vote_t = 1, vote_a = 1, k_steps = 32;
+    uint32_t lds_pad = 0;
 };
 
 static int ensure(void** p, size_t* have, size_t want) {
@@ -129,11 +130,12 @@ extern "C" int mi_ctx_create(int device, mi_ctx** out) {
     HIP_TRY(hipStreamCreate(&c->stream));
     HIP_TRY(hipEventCreate(&c->ev_start));
     HIP_TRY(hipEventCreate(&c->ev_stop));
-    HIP_TRY(hipMalloc((void**)&c->d_diag, 8 * sizeof(unsigned long long)));
+    HIP_TRY(hipMalloc((void**)&c->d_diag, 16 * sizeof(unsigned long long)));
     // developer knobs of the voted kernel (defaults are the tuned values)
     if (const char* e = getenv("MI_RT_VOTE_T")) c->vote_t = (uint32_t)atoi(e);
     if (const char* e = getenv("MI_RT_VOTE_A")) c->vote_a = (uint32_t)atoi(e);
     if (const char* e = getenv("MI_RT_KSTEPS")) c->k_steps = (uint32_t)atoi(e);
+    if (const char* e = getenv("MI_RT_LDS_PAD_KB")) c->lds_pad = (uint32_t)atoi(e) * 1024u;   // occupancy experiments
     if (c->vote_t < 1) c->vote_t = 1;
     if (c->k_steps < 1) c->k_steps = 1;
     *out = c;
@@ -512,13 +514,13 @@ static int render_tiles(mi_ctx* c, const mi_camera_desc* cam, const mi_render_op
     uint32_t n_blocks = padded * (uint32_t)kBlocksPerTile;
     if (diag) {
         a.diag = c->d_diag;
-        HIP_TRY(hipMemsetAsync(c->d_diag, 0, 8 * sizeof(unsigned long long), stream));
+        HIP_TRY(hipMemsetAsync(c->d_diag, 0, 16 * sizeof(unsigned long long), stream));
     }
     HIP_TRY(hipEventRecord(c->ev_start, stream));
     if (pooled)
         HIP_TRY(launch_megakernel_pooled(a, padded, lds, a.sig != nullptr, diag, c->lds_bytes, stream));
     else if (variant == MI_VARIANT_VOTED || variant == MI_VARIANT_VOTED_DIAG)
-        HIP_TRY(launch_megakernel_voted(a, n_blocks, lds, a.sig != nullptr, diag, c->lds_bytes, stream));
+        HIP_TRY(launch_megakernel_voted(a, n_blocks, lds, a.sig != nullptr, diag, c->lds_bytes + c->lds_pad, stream));
     else
         HIP_TRY(launch_megakernel(a, n_blocks, lds, park, a.sig != nullptr, c->lds_bytes, stream));
     HIP_TRY(hipEventRecord(c->ev_stop, stream));
@@ -575,11 +577,11 @@ extern "C" int mi_last_kernel_ms(mi_ctx* c, float* ms) {
     return MI_OK;
 }
 
-extern "C" int mi_last_diag(mi_ctx* c, uint64_t* out8) {
-    if (!c || !out8) return fail(MI_ERR_INVALID, "mi_last_diag: bad argument");
+extern "C" int mi_last_diag(mi_ctx* c, uint64_t* out16) {
+    if (!c || !out16) return fail(MI_ERR_INVALID, "mi_last_diag: bad argument");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(out8, c->d_diag, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out16, c->d_diag, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return MI_OK;
 }
 

@@ -887,13 +887,15 @@ __global__ __launch_bounds__(kBlock, PT_MIN_WAVES) void pt_megakernel_voted(K1Ar
     float tbt = 0.0f, tbu = 0.0f, tbv = 0.0f;
 
     unsigned long long dg_tripsA = 0, dg_lanesA = 0, dg_tripsI = 0, dg_lanesI = 0, dg_tripsL = 0, dg_lanesL = 0, dg_tripsB = 0;
+    unsigned long long dg_cycA = 0, dg_cycB = 0, dg_t0 = 0;   // DIAG only: shader-clock cycles spent in A / B trips
 
     while (true) {
-        const int nA = __popcll(__ballot(state == ST_A));
-        const int nT = __popcll(__ballot(state == ST_TRAV));
+        const int nA = __popcll(__builtin_amdgcn_ballot_w64(state == ST_A));
+        const int nT = __popcll(__builtin_amdgcn_ballot_w64(state == ST_TRAV));
         if (nA + nT == 0) break;
         const bool run_b = (nT > 0) && (nT * vote_t >= nA * vote_a);
 
+        if (DIAG) dg_t0 = __builtin_amdgcn_s_memtime();
         if (!run_b) {
             if (DIAG) { dg_tripsA++; dg_lanesA += (unsigned long long)nA; }
             if (state == ST_A) {
@@ -955,27 +957,28 @@ __global__ __launch_bounds__(kBlock, PT_MIN_WAVES) void pt_megakernel_voted(K1Ar
             // ---- B-trip: BVHNode::intersect_ray (geometry.rs:94-119), k_steps voted micro-steps ----
             for (int k = 0; k < k_steps; k++) {
                 const bool in_t = (state == ST_TRAV);
-                float4 n0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), n1 = n0;
-                int tri = -1;
-                if (in_t) { B.node(ti, n0, n1); tri = __float_as_int(n1.w); }
-                const bool at_leaf = in_t && tri >= 0, at_inner = in_t && tri < 0;
-                const int n_leaf = __popcll(__ballot(at_leaf)), n_inner = __popcll(__ballot(at_inner));
+                // every lane fetches a node (lanes outside a BVH read node 0 of the pool: harmless,
+                // and it keeps the fetch branch-free); the 1-bit ballots feed s_bcnt1 directly
+                float4 n0, n1;
+                B.node(in_t ? ti : 0, n0, n1);
+                const int tri = __float_as_int(n1.w);
+                const bool at_leaf = in_t & (tri >= 0), at_inner = in_t & (tri < 0);
+                const int n_leaf = __popcll(__builtin_amdgcn_ballot_w64(at_leaf));
+                const int n_inner = __popcll(__builtin_amdgcn_ballot_w64(at_inner));
                 if (n_leaf + n_inner == 0) break;
                 if (n_inner >= n_leaf) {
                     if (DIAG) { dg_tripsI++; dg_lanesI += (unsigned long long)n_inner; }
-                    if (at_inner) {
-                        bool hit = slab(mk3(n0.x, n0.y, n0.z), mk3(n1.x, n1.y, n1.z), too, tinv, t_min, tbt);   // :103
-                        ti = hit ? ti + 1 : __float_as_int(n0.w);
-                    }
+                    bool hit = slab(mk3(n0.x, n0.y, n0.z), mk3(n1.x, n1.y, n1.z), too, tinv, t_min, tbt);   // :103
+                    int nxt = hit ? ti + 1 : __float_as_int(n0.w);
+                    ti = at_inner ? nxt : ti;
                 } else {
                     if (DIAG) { dg_tripsL++; dg_lanesL += (unsigned long long)n_leaf; }
                     if (at_leaf) {
                         f3 a, e1, e2;
                         B.tri(ttb + tri, a, e1, e2);
                         float t, u, v;
-                        if (tri_t(too, tod, a, e1, e2, t_min, tbt, t, u, v)) {                                  // :97
-                            tbt = t; tbtri = tri; tbu = u; tbv = v;
-                        }
+                        bool ok = tri_t(too, tod, a, e1, e2, t_min, tbt, t, u, v);                          // :97
+                        tbt = ok ? t : tbt; tbtri = ok ? tri : tbtri; tbu = ok ? u : tbu; tbv = ok ? v : tbv;
                         ti = ti + 1;
                     }
                 }
@@ -991,6 +994,7 @@ __global__ __launch_bounds__(kBlock, PT_MIN_WAVES) void pt_megakernel_voted(K1Ar
                 }
             }
         }
+        if (DIAG) { unsigned long long dt = __builtin_amdgcn_s_memtime() - dg_t0; if (run_b) dg_cycB += dt; else dg_cycA += dt; }
     }
 
     float n = (float)C.spp;
@@ -1003,6 +1007,7 @@ __global__ __launch_bounds__(kBlock, PT_MIN_WAVES) void pt_megakernel_voted(K1Ar
         atomicAdd(&A.diag[2], dg_tripsI); atomicAdd(&A.diag[3], dg_lanesI);
         atomicAdd(&A.diag[4], dg_tripsL); atomicAdd(&A.diag[5], dg_lanesL);
         atomicAdd(&A.diag[6], dg_tripsB); atomicAdd(&A.diag[7], 1ull);
+        atomicAdd(&A.diag[8], dg_cycA); atomicAdd(&A.diag[9], dg_cycB);
     }
 }
 

@@ -122,9 +122,10 @@ class Context:
 
     def last_diag(self):
         """Counters of the last MI_VARIANT_VOTED_DIAG launch as a dict (diagnostic)."""
-        out = (C.c_uint64 * 8)()
+        out = (C.c_uint64 * 16)()
         abi.check(self._lib.mi_last_diag(self._h, out))
-        k = ["a_trips", "a_lanes", "inner_trips", "inner_lanes", "leaf_trips", "leaf_lanes", "b_trips", "waves"]
+        k = ["a_trips", "a_lanes", "inner_trips", "inner_lanes", "leaf_trips", "leaf_lanes", "b_trips", "waves",
+             "a_cycles", "b_cycles"]
         return dict(zip(k, [int(v) for v in out]))
 
     def last_kernel_ms(self) -> float:

@@ -237,9 +237,10 @@ int  mi_tonemap_device(mi_ctx* ctx, const mi_camera_desc* cam,
 int  mi_last_kernel_ms(mi_ctx* ctx, float* ms);
 
 /* Counters of the most recent *_DIAG launch (synchronises the device):
- * out8 = { A trips, sum of lanes in A trips, interior-step trips, lanes, leaf-step trips,
- *          lanes, B trips, waves }.  active-lane fraction of a phase = lanes / (64 * trips). */
-int  mi_last_diag(mi_ctx* ctx, uint64_t* out8);
+ * out16 = { A trips, sum of lanes in A trips, interior-step trips, lanes, leaf-step trips,
+ *           lanes, B trips, waves, shader-clock cycles in A trips, in B trips, 0... }.
+ * active-lane fraction of a phase = lanes / (64 * trips). */
+int  mi_last_diag(mi_ctx* ctx, uint64_t* out16);
 
 /* Thread-local message of the most recent failure in this thread. */
 const char* mi_last_error(void);
