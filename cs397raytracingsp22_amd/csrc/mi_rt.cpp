@@ -95,7 +95,7 @@ struct mi_ctx {
     uint32_t* d_sigi = nullptr; size_t sigi_bytes = 0;
     unsigned long long* d_diag = nullptr;    // 8 counters of the diagnostic variant
     void* d_park = nullptr; size_t park_bytes = 0;   // parked path records of the POOLED kernel
-    uint32_t vote_t = 1, vote_a = 1, k_steps = 32;
+    uint32_t vote_t = 2, vote_a = 1, k_steps = 8;
     uint32_t lds_pad = 0;
 };
 

@@ -531,21 +531,23 @@ __device__ __forceinline__ void consider_list(Best& b, bool ok, float t, int obj
 __device__ __forceinline__ void intersect_list(const DScene& S, f3 o, f3 d, float t_min, float t_max, Rng& rng, Best& best) {
     auto L = S.list;
     int k = 0;
-    {   // Triangle::intersect_ray geometry.rs:431-450
+    {   // Triangle::intersect_ray geometry.rs:431-450.  Two triangles per trip: the two
+        // Moller-Trumbore chains (cross, dot, correctly rounded 1/g, ...) are independent, so the
+        // in-order issue overlaps their latencies; `consider` is applied in list order.
         const int end = S.n_list_tri;
-        float c[12]; int ci = L[k].index;
-#pragma unroll
-        for (int j = 0; j < 12; j++) c[j] = L[k].f[j];
+        for (; k + 1 < end; k += 2) {
+            auto r0 = &L[k]; auto r1 = &L[k + 1];
+            float t0, u0, v0, t1, u1, v1;
+            bool ok0 = tri_t(o, d, ld3(r0->f), ld3(r0->f + 3), ld3(r0->f + 6), t_min, t_max, t0, u0, v0);
+            bool ok1 = tri_t(o, d, ld3(r1->f), ld3(r1->f + 3), ld3(r1->f + 6), t_min, t_max, t1, u1, v1);
+            consider_list(best, ok0, t0, r0->index);
+            consider_list(best, ok1, t1, r1->index);
+        }
         for (; k < end; k++) {
-            float n[12]; int ni = L[k + 1].index;            // one record of slack is allocated past the end
-#pragma unroll
-            for (int j = 0; j < 12; j++) n[j] = L[k + 1].f[j];
-            float t, u, v;
-            bool ok = tri_t(o, d, mk3(c[0], c[1], c[2]), mk3(c[3], c[4], c[5]), mk3(c[6], c[7], c[8]), t_min, t_max, t, u, v);
-            consider_list(best, ok, t, ci);
-            ci = ni;
-#pragma unroll
-            for (int j = 0; j < 12; j++) c[j] = n[j];
+            auto r0 = &L[k];
+            float t0, u0, v0;
+            bool ok0 = tri_t(o, d, ld3(r0->f), ld3(r0->f + 3), ld3(r0->f + 6), t_min, t_max, t0, u0, v0);
+            consider_list(best, ok0, t0, r0->index);
         }
     }
     {   // Sphere::intersect_ray geometry.rs:395-413
@@ -887,7 +889,7 @@ __global__ __launch_bounds__(kBlock, PT_MIN_WAVES) void pt_megakernel_voted(K1Ar
     float tbt = 0.0f, tbu = 0.0f, tbv = 0.0f;
 
     unsigned long long dg_tripsA = 0, dg_lanesA = 0, dg_tripsI = 0, dg_lanesI = 0, dg_tripsL = 0, dg_lanesL = 0, dg_tripsB = 0;
-    unsigned long long dg_cycA = 0, dg_cycB = 0, dg_t0 = 0;   // DIAG only: shader-clock cycles spent in A / B trips
+    unsigned long long dg_cycA = 0, dg_cycB = 0, dg_t0 = 0, dg_cycShade = 0, dg_cycGen = 0, dg_cycList = 0, dg_t1 = 0;   // DIAG only: shader-clock cycles spent in A / B trips
 
     while (true) {
         const int nA = __popcll(__builtin_amdgcn_ballot_w64(state == ST_A));
@@ -900,6 +902,7 @@ __global__ __launch_bounds__(kBlock, PT_MIN_WAVES) void pt_megakernel_voted(K1Ar
             if (DIAG) { dg_tripsA++; dg_lanesA += (unsigned long long)nA; }
             if (state == ST_A) {
                 // ---- (a) Scene::shade_ray, one level, for the intersection found last trip ----
+                if (DIAG) dg_t1 = __builtin_amdgcn_s_memtime();
                 if (pending) {
                     pending = false;
                     bool end_path;
@@ -931,6 +934,7 @@ __global__ __launch_bounds__(kBlock, PT_MIN_WAVES) void pt_megakernel_voted(K1Ar
                     }
                 }
                 // ---- (b) Camera::generate_rays for the next sample ----
+                if (DIAG) { unsigned long long t = __builtin_amdgcn_s_memtime(); dg_cycShade += t - dg_t1; dg_t1 = t; }
                 if (fresh) {
                     if (sample >= spp) state = ST_DEAD;
                     else {
@@ -941,6 +945,7 @@ __global__ __launch_bounds__(kBlock, PT_MIN_WAVES) void pt_megakernel_voted(K1Ar
                     }
                 }
                 // ---- (c) Scene::intersect_ray: the object list, then the mesh roots ----
+                if (DIAG) { unsigned long long t = __builtin_amdgcn_s_memtime(); dg_cycGen += t - dg_t1; dg_t1 = t; }
                 if (state == ST_A) {
                     best.obj = -1; best.t = 0.0f; best.tri = -1; best.u = best.v = 0.0f;
                     intersect_list(S, P.o, P.d, t_min, t_max, P.rng, best);
@@ -951,26 +956,44 @@ __global__ __launch_bounds__(kBlock, PT_MIN_WAVES) void pt_megakernel_voted(K1Ar
                         pending = true;
                     }
                 }
+                if (DIAG) dg_cycList += __builtin_amdgcn_s_memtime() - dg_t1;
             }
         } else {
             if (DIAG) dg_tripsB++;
-            // ---- B-trip: BVHNode::intersect_ray (geometry.rs:94-119), k_steps voted micro-steps ----
+            // ---- B-trip: BVHNode::intersect_ray (geometry.rs:94-119) ----
+            // Each lane inside a BVH keeps its CURRENT NODE in registers (c0, c1).  One vote decides
+            // between a BURST of up to kBurst interior steps and one leaf step.  Inside a burst there
+            // is no vote and no branch: both possible successors (left child ti+1, skip link) are
+            // fetched from LDS while the slab test computes, and the result selects one of them.  A
+            // lane that reaches a leaf or the end of its tree just sits out the rest of the burst.
+            constexpr int kBurst = 4;
+            const int last_node = S.n_nodes - 1;
+            float4 c0, c1;
+            B.node((state == ST_TRAV) ? ti : 0, c0, c1);
             for (int k = 0; k < k_steps; k++) {
                 const bool in_t = (state == ST_TRAV);
-                // every lane fetches a node (lanes outside a BVH read node 0 of the pool: harmless,
-                // and it keeps the fetch branch-free); the 1-bit ballots feed s_bcnt1 directly
-                float4 n0, n1;
-                B.node(in_t ? ti : 0, n0, n1);
-                const int tri = __float_as_int(n1.w);
+                const int tri = __float_as_int(c1.w);
                 const bool at_leaf = in_t & (tri >= 0), at_inner = in_t & (tri < 0);
                 const int n_leaf = __popcll(__builtin_amdgcn_ballot_w64(at_leaf));
                 const int n_inner = __popcll(__builtin_amdgcn_ballot_w64(at_inner));
                 if (n_leaf + n_inner == 0) break;
                 if (n_inner >= n_leaf) {
                     if (DIAG) { dg_tripsI++; dg_lanesI += (unsigned long long)n_inner; }
-                    bool hit = slab(mk3(n0.x, n0.y, n0.z), mk3(n1.x, n1.y, n1.z), too, tinv, t_min, tbt);   // :103
-                    int nxt = hit ? ti + 1 : __float_as_int(n0.w);
-                    ti = at_inner ? nxt : ti;
+#pragma unroll
+                    for (int j = 0; j < kBurst; j++) {
+                        const bool act = in_t & (ti < tend) & (__float_as_int(c1.w) < 0);
+                        const int skip = __float_as_int(c0.w);
+                        float4 l0, l1, s0, s1;
+                        B.node(act ? min(ti + 1, last_node) : 0, l0, l1);
+                        B.node(act ? min(skip, last_node) : 0, s0, s1);
+                        const bool hit = slab(mk3(c0.x, c0.y, c0.z), mk3(c1.x, c1.y, c1.z), too, tinv, t_min, tbt);   // :103
+                        const bool go = act & hit, stay = !act;
+                        ti = stay ? ti : (go ? ti + 1 : skip);
+                        c0.x = stay ? c0.x : (go ? l0.x : s0.x); c0.y = stay ? c0.y : (go ? l0.y : s0.y);
+                        c0.z = stay ? c0.z : (go ? l0.z : s0.z); c0.w = stay ? c0.w : (go ? l0.w : s0.w);
+                        c1.x = stay ? c1.x : (go ? l1.x : s1.x); c1.y = stay ? c1.y : (go ? l1.y : s1.y);
+                        c1.z = stay ? c1.z : (go ? l1.z : s1.z); c1.w = stay ? c1.w : (go ? l1.w : s1.w);
+                    }
                 } else {
                     if (DIAG) { dg_tripsL++; dg_lanesL += (unsigned long long)n_leaf; }
                     if (at_leaf) {
@@ -980,6 +1003,7 @@ __global__ __launch_bounds__(kBlock, PT_MIN_WAVES) void pt_megakernel_voted(K1Ar
                         bool ok = tri_t(too, tod, a, e1, e2, t_min, tbt, t, u, v);                          // :97
                         tbt = ok ? t : tbt; tbtri = ok ? tri : tbtri; tbu = ok ? u : tbu; tbv = ok ? v : tbv;
                         ti = ti + 1;
+                        B.node(min(ti, last_node), c0, c1);
                     }
                 }
                 if (in_t && ti >= tend) {
@@ -988,6 +1012,7 @@ __global__ __launch_bounds__(kBlock, PT_MIN_WAVES) void pt_megakernel_voted(K1Ar
                     tm++;
                     if (enter_next_mesh(S, B, tm, P.o, P.d, t_min, t_max, too, tod, tinv, ti, tend, ttb)) {
                         tbt = t_max; tbtri = -1; tbu = tbv = 0.0f;
+                        B.node(ti, c0, c1);
                     } else {
                         state = ST_A; pending = true;
                     }
@@ -1008,6 +1033,7 @@ __global__ __launch_bounds__(kBlock, PT_MIN_WAVES) void pt_megakernel_voted(K1Ar
         atomicAdd(&A.diag[4], dg_tripsL); atomicAdd(&A.diag[5], dg_lanesL);
         atomicAdd(&A.diag[6], dg_tripsB); atomicAdd(&A.diag[7], 1ull);
         atomicAdd(&A.diag[8], dg_cycA); atomicAdd(&A.diag[9], dg_cycB);
+        atomicAdd(&A.diag[10], dg_cycShade); atomicAdd(&A.diag[11], dg_cycGen); atomicAdd(&A.diag[12], dg_cycList);
     }
 }
 

@@ -23,6 +23,9 @@ for dv in (4, 6):
     for k in ("a", "inner", "leaf"):
         t, l = d[k + "_trips"], d[k + "_lanes"]
         print(f"  {k}: trips/wave={t / max(1, d['waves']):.0f} active-lane fraction={l / max(1, 64 * t):.3f}")
+    if d.get("shade_cycles"):
+        tot = d["shade_cycles"] + d["gen_cycles"] + d["list_cycles"]
+        print(f"  A split: shade {d['shade_cycles'] / tot:.2f}  gen {d['gen_cycles'] / tot:.2f}  list+root {d['list_cycles'] / tot:.2f}  (per trip {d['shade_cycles'] / d['a_trips']:.0f} / {d['gen_cycles'] / d['a_trips']:.0f} / {d['list_cycles'] / d['a_trips']:.0f} cycles)")
     if d.get("a_cycles"):
         print(f"  cycles: A {d['a_cycles'] / d['waves'] / 1e6:.2f} M/wave ({d['a_cycles'] / max(1, d['a_trips']):.0f} per trip)  "
               f"B {d['b_cycles'] / d['waves'] / 1e6:.2f} M/wave ({d['b_cycles'] / max(1, d['inner_trips'] + d['leaf_trips']):.0f} per micro-step)")
