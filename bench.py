@@ -87,6 +87,8 @@ def main():
     ap.add_argument("--spp", type=int, default=0, help="override samples per pixel (debug; invalidates the metric)")
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
+    ap.add_argument("--same-gpu", action="store_true", help="rehearsal: every rank uses GPU 0 (with --backend gloo)")
     args = ap.parse_args()
 
     import torch
@@ -99,11 +101,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if args.same_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device(f"cuda:{local_rank}")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=device)
+        else:
+            dist.init_process_group(backend=args.backend)
 
     if args.config == "cfg1":
         sc, cfgname = scenes.config1(), "cfg1"
@@ -156,7 +163,7 @@ def main():
             "metric": "Msamples/sec (=rays/sec) at 1080p Cornell+teapot, 256 spp; 1/2/4/8 GPU",
             "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32", "data": "synthetic", "backend": (args.backend if world > 1 else None),
             "config": {"workload": f"{args.config}: Cornell box (10 Triangle + 2 Sphere) + teapot StaticMesh (240 tris, reference-topology BVH)"
                                    if cfgname == "cfg2" else "cfg1: Cornell box (10 Triangle + 2 Sphere)",
                        "width": cam.screen_width, "height": cam.screen_height, "spp": cam.aa_sample_count,

@@ -58,6 +58,10 @@ def gather_compact(local, world: int, rank: int, dst: int = 0, group=None):
 
     if world == 1:
         return local.unsqueeze(0)
+    if local.is_cuda and dist.get_backend(group) == "gloo":
+        # rehearsal only (two ranks sharing one GPU): gloo has no device gather, stage through the host
+        host = gather_compact(local.cpu(), world, rank, dst, group)
+        return host.to(local.device) if host is not None else None
     if rank == dst:
         out = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
         dist.gather(local, gather_list=[out[r] for r in range(world)], dst=dst, group=group)

@@ -134,3 +134,14 @@ def test_gather_path_world_size_2_gloo(tmp_path):
                          capture_output=True, text=True, env=env, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "GLOO_OK 2" in out.stdout
+
+
+def test_png_writer_round_trip(tmp_path):
+    from cs397raytracingsp22_amd.image import save_png
+    rng = np.random.default_rng(2)
+    img = rng.integers(0, 256, size=(37, 53, 3), dtype=np.uint8)
+    path = tmp_path / "x.png"
+    save_png(str(path), img)
+    from PIL import Image
+    back = np.asarray(Image.open(path).convert("RGB"))
+    assert np.array_equal(back, img)
