@@ -20,10 +20,10 @@
 //   * mesh BVHs are traversed STACKLESS through skip links (the reference's fixed
 //     left-then-right order, geometry.rs:105-115, makes this exact), nodes and triangles
 //     staged into LDS when they fit (teapot: 479 nodes + 240 triangles = 26.8 KB).
-//   * PARKED variant: phases are voted with __ballot/__popcll — lanes whose ray enters a
-//     mesh root box park, the rest keep tracing; the wave runs the traversal loop only
-//     when enough lanes are parked, so the long, divergent BVH loop runs at high lane
-//     utilisation.
+//   * VOTED variant (default, pt_megakernel_voted): each lane is a state machine and every
+//     trip of the wave-wide loop votes with __ballot/__popcll which phase runs — the BVH node
+//     step, not the segment, is the scheduling unit.  SIMPLE / PARKED (pt_megakernel) and
+//     POOLED are kept as structural cross-checks and recorded experiments.
 //
 // Numerics: every expression is written in the reference's evaluation order; the file
 // is compiled with -ffp-contract=off (Rust never fuses a*b+c) and HIP's default
@@ -889,7 +889,8 @@ __global__ __launch_bounds__(kBlock, PT_MIN_WAVES) void pt_megakernel_voted(K1Ar
     float tbt = 0.0f, tbu = 0.0f, tbv = 0.0f;
 
     unsigned long long dg_tripsA = 0, dg_lanesA = 0, dg_tripsI = 0, dg_lanesI = 0, dg_tripsL = 0, dg_lanesL = 0, dg_tripsB = 0;
-    unsigned long long dg_cycA = 0, dg_cycB = 0, dg_t0 = 0, dg_cycShade = 0, dg_cycGen = 0, dg_cycList = 0, dg_t1 = 0;   // DIAG only: shader-clock cycles spent in A / B trips
+    unsigned long long dg_cycA = 0, dg_cycB = 0, dg_t0 = 0, dg_cycShade = 0, dg_cycGen = 0, dg_cycList = 0, dg_t1 = 0;
+    unsigned long long dg_slabs = 0, dg_roots = 0;             // DIAG: slab tests inside trees / at mesh roots   // DIAG only: shader-clock cycles spent in A / B trips
 
     while (true) {
         const int nA = __popcll(__builtin_amdgcn_ballot_w64(state == ST_A));
@@ -900,6 +901,7 @@ __global__ __launch_bounds__(kBlock, PT_MIN_WAVES) void pt_megakernel_voted(K1Ar
         if (DIAG) dg_t0 = __builtin_amdgcn_s_memtime();
         if (!run_b) {
             if (DIAG) { dg_tripsA++; dg_lanesA += (unsigned long long)nA; }
+            bool did_list = false;
             if (state == ST_A) {
                 // ---- (a) Scene::shade_ray, one level, for the intersection found last trip ----
                 if (DIAG) dg_t1 = __builtin_amdgcn_s_memtime();
@@ -949,6 +951,7 @@ __global__ __launch_bounds__(kBlock, PT_MIN_WAVES) void pt_megakernel_voted(K1Ar
                 if (state == ST_A) {
                     best.obj = -1; best.t = 0.0f; best.tri = -1; best.u = best.v = 0.0f;
                     intersect_list(S, P.o, P.d, t_min, t_max, P.rng, best);
+                    if (DIAG) did_list = true;
                     tm = 0;
                     if (enter_next_mesh(S, B, tm, P.o, P.d, t_min, t_max, too, tod, tinv, ti, tend, ttb)) {
                         state = ST_TRAV; tbt = t_max; tbtri = -1; tbu = tbv = 0.0f;
@@ -958,6 +961,7 @@ __global__ __launch_bounds__(kBlock, PT_MIN_WAVES) void pt_megakernel_voted(K1Ar
                 }
                 if (DIAG) dg_cycList += __builtin_amdgcn_s_memtime() - dg_t1;
             }
+            if (DIAG) dg_roots += (unsigned long long)__popcll(__builtin_amdgcn_ballot_w64(did_list));   // wave-uniform
         } else {
             if (DIAG) dg_tripsB++;
             // ---- B-trip: BVHNode::intersect_ray (geometry.rs:94-119) ----
@@ -982,6 +986,7 @@ __global__ __launch_bounds__(kBlock, PT_MIN_WAVES) void pt_megakernel_voted(K1Ar
 #pragma unroll
                     for (int j = 0; j < kBurst; j++) {
                         const bool act = in_t & (ti < tend) & (__float_as_int(c1.w) < 0);
+                        if (DIAG) dg_slabs += (unsigned long long)__popcll(__builtin_amdgcn_ballot_w64(act));
                         const int skip = __float_as_int(c0.w);
                         float4 l0, l1, s0, s1;
                         B.node(act ? min(ti + 1, last_node) : 0, l0, l1);
@@ -1034,6 +1039,7 @@ __global__ __launch_bounds__(kBlock, PT_MIN_WAVES) void pt_megakernel_voted(K1Ar
         atomicAdd(&A.diag[6], dg_tripsB); atomicAdd(&A.diag[7], 1ull);
         atomicAdd(&A.diag[8], dg_cycA); atomicAdd(&A.diag[9], dg_cycB);
         atomicAdd(&A.diag[10], dg_cycShade); atomicAdd(&A.diag[11], dg_cycGen); atomicAdd(&A.diag[12], dg_cycList);
+        atomicAdd(&A.diag[13], dg_slabs); atomicAdd(&A.diag[14], dg_roots);
     }
 }
 

@@ -125,7 +125,7 @@ class Context:
         out = (C.c_uint64 * 16)()
         abi.check(self._lib.mi_last_diag(self._h, out))
         k = ["a_trips", "a_lanes", "inner_trips", "inner_lanes", "leaf_trips", "leaf_lanes", "b_trips", "waves",
-             "a_cycles", "b_cycles", "shade_cycles", "gen_cycles", "list_cycles"]
+             "a_cycles", "b_cycles", "shade_cycles", "gen_cycles", "list_cycles", "slab_tests", "segments"]
         return dict(zip(k, [int(v) for v in out]))
 
     def last_kernel_ms(self) -> float:

@@ -238,7 +238,8 @@ int  mi_last_kernel_ms(mi_ctx* ctx, float* ms);
 
 /* Counters of the most recent *_DIAG launch (synchronises the device):
  * out16 = { A trips, sum of lanes in A trips, interior-step trips, lanes, leaf-step trips,
- *           lanes, B trips, waves, shader-clock cycles in A trips, in B trips, 0... }.
+ *           lanes, B trips, waves, shader-clock cycles in A trips, in B trips, cycles in A's
+ *           shade / regenerate / list sections, slab tests inside trees, path segments, 0 }.
  * active-lane fraction of a phase = lanes / (64 * trips). */
 int  mi_last_diag(mi_ctx* ctx, uint64_t* out16);
 

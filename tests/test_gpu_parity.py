@@ -55,3 +55,19 @@ def test_config2_ragged_edges_and_seed(gpu_ctx, orc):
 
 def test_defocus(gpu_ctx, orc):
     compare(gpu_ctx, orc, scenes.config2(96, 64, 16, 10, lens_radius=0.05))
+
+
+def test_work_counters_equal_the_oracle(gpu_ctx, orc):
+    """Structural parity: the diagnostic build walks exactly the reference's
+    work — same number of path segments, of AABB slab tests and of triangle tests as the oracle
+    counts on the reference BVH topology."""
+    sc = scenes.config2(96, 64, 16, 10)
+    flat = sc.flatten()
+    gpu_ctx.upload(flat)
+    gpu_ctx.render(sc.camera, seed=5, want_u8=False, variant=abi.MI_VARIANT_VOTED_DIAG)
+    d = gpu_ctx.last_diag()
+    _, _, _, cnt = orc.OracleScene(flat).render(sc.camera, seed=5, want_u8=False, want_sig=False, want_counters=True)
+    assert d["segments"] == cnt["segments"]
+    assert d["leaf_lanes"] == cnt["tri_tests"]
+    # the oracle counts the root box test of every mesh call; the kernel does it in the A phase
+    assert d["slab_tests"] + cnt["mesh_tests"] == cnt["box_tests"]
