@@ -23,7 +23,7 @@ MI_OBJ_SPHERE, MI_OBJ_TRIANGLE, MI_OBJ_PLANE, MI_OBJ_VOLUME, MI_OBJ_MESH = range
 MI_PROJ_ORTHOGRAPHIC, MI_PROJ_PERSPECTIVE = 0, 1
 MI_SHADE_PHONG, MI_SHADE_PATHTRACE = 0, 1
 MI_VARIANT_DEFAULT, MI_VARIANT_SIMPLE, MI_VARIANT_PARKED, MI_VARIANT_VOTED, MI_VARIANT_VOTED_DIAG = 0, 1, 2, 3, 4
-MI_VARIANT_POOLED, MI_VARIANT_POOLED_DIAG = 5, 6
+MI_VARIANT_POOLED, MI_VARIANT_POOLED_DIAG, MI_VARIANT_WAVEFRONT = 5, 6, 7
 
 f3 = C.c_float * 3
 f16 = C.c_float * 16
@@ -103,7 +103,7 @@ class mi_stats(C.Structure):
 EXPORTS = [
     "mi_ctx_create", "mi_ctx_destroy", "mi_scene_upload", "mi_render", "mi_compact_size",
     "mi_render_tiles_device", "mi_unpermute_device", "mi_tonemap_device", "mi_last_kernel_ms",
-    "mi_last_diag", "mi_last_error", "mi_abi_version",
+    "mi_last_pipeline_ms", "mi_last_diag", "mi_last_error", "mi_abi_version",
 ]
 
 _lib = None
@@ -154,6 +154,8 @@ def load() -> C.CDLL:
     lib.mi_tonemap_device.restype = C.c_int
     lib.mi_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     lib.mi_last_kernel_ms.restype = C.c_int
+    lib.mi_last_pipeline_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    lib.mi_last_pipeline_ms.restype = C.c_int
     lib.mi_last_diag.argtypes = [vp, C.POINTER(C.c_uint64)]
     lib.mi_last_diag.restype = C.c_int
     lib.mi_last_error.argtypes = []

@@ -36,6 +36,9 @@ hipError_t launch_megakernel_voted(const K1Args& args, uint32_t n_blocks, bool l
 hipError_t launch_megakernel_pooled(const K1Args& args, uint32_t tiles_padded, bool lds, bool sig, bool diag,
                                     size_t lds_bytes, hipStream_t stream);
 size_t pooled_park_bytes(uint32_t tiles_padded);
+hipError_t launch_wf_main(const WfArgs& a, uint32_t n_threads, bool sig, hipStream_t stream);
+hipError_t launch_wf_trav(const WfArgs& a, uint32_t n_blocks, bool lds, size_t lds_bytes, hipStream_t stream);
+hipError_t launch_wf_reduce(const WfArgs& a, bool first_batch, bool last_batch, hipStream_t stream);
 hipError_t launch_unpermute(const float* gathered, float* image, uint32_t width, uint32_t height, uint32_t tiles_x,
                             uint32_t world, uint32_t tiles_padded, hipStream_t stream);
 hipError_t launch_sig_unpermute(const uint32_t* gathered, uint32_t* image, uint32_t width, uint32_t height,
@@ -95,6 +98,17 @@ struct mi_ctx {
     uint32_t* d_sigi = nullptr; size_t sigi_bytes = 0;
     unsigned long long* d_diag = nullptr;    // 8 counters of the diagnostic variant
     void* d_park = nullptr; size_t park_bytes = 0;   // parked path records of the POOLED kernel
+    // wavefront pipeline buffers
+    void* d_wf_a = nullptr; size_t wf_a_bytes = 0;   // path state ping
+    void* d_wf_b = nullptr; size_t wf_b_bytes = 0;   // path state pong
+    void* d_wf_q = nullptr; size_t wf_q_bytes = 0;   // traversal queue
+    void* d_wf_samp = nullptr; size_t wf_samp_bytes = 0;
+    void* d_wf_acc = nullptr; size_t wf_acc_bytes = 0;
+    uint32_t* d_wf_cnt = nullptr;
+    uint64_t wf_max_paths = 0;                       // paths per batch; 0 = size from free HBM (MI_RT_WF_PATHS overrides)
+    std::vector<hipEvent_t> wf_ev;                   // event pool for per-kernel timing of the pipeline
+    float wf_ms[4] = { 0, 0, 0, 0 };                 // last frame: wf_main, wf_trav, wf_reduce totals (ms), launches
+    int n_cus = 256;
     uint32_t vote_t = 2, vote_a = 1, k_steps = 8;
     uint32_t lds_pad = 0;
 };
@@ -135,6 +149,9 @@ extern "C" int mi_ctx_create(int device, mi_ctx** out) {
     if (const char* e = getenv("MI_RT_VOTE_T")) c->vote_t = (uint32_t)atoi(e);
     if (const char* e = getenv("MI_RT_VOTE_A")) c->vote_a = (uint32_t)atoi(e);
     if (const char* e = getenv("MI_RT_KSTEPS")) c->k_steps = (uint32_t)atoi(e);
+    if (const char* e = getenv("MI_RT_WF_PATHS")) c->wf_max_paths = (uint64_t)atoll(e);
+    c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    HIP_TRY(hipMalloc((void**)&c->d_wf_cnt, (6 * 256 + 32) * sizeof(uint32_t)));
     if (const char* e = getenv("MI_RT_LDS_PAD_KB")) c->lds_pad = (uint32_t)atoi(e) * 1024u;   // occupancy experiments
     if (c->vote_t < 1) c->vote_t = 1;
     if (c->k_steps < 1) c->k_steps = 1;
@@ -154,6 +171,13 @@ extern "C" void mi_ctx_destroy(mi_ctx* c) {
     if (c->d_sigi) (void)hipFree(c->d_sigi);
     if (c->d_diag) (void)hipFree(c->d_diag);
     if (c->d_park) (void)hipFree(c->d_park);
+    if (c->d_wf_a) (void)hipFree(c->d_wf_a);
+    if (c->d_wf_b) (void)hipFree(c->d_wf_b);
+    if (c->d_wf_q) (void)hipFree(c->d_wf_q);
+    if (c->d_wf_samp) (void)hipFree(c->d_wf_samp);
+    if (c->d_wf_acc) (void)hipFree(c->d_wf_acc);
+    if (c->d_wf_cnt) (void)hipFree(c->d_wf_cnt);
+    for (hipEvent_t e : c->wf_ev) (void)hipEventDestroy(e);
     if (c->ev_start) (void)hipEventDestroy(c->ev_start);
     if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -477,6 +501,140 @@ static void make_camera(const mi_camera_desc* cam, DCamera* C) {
     C->width = cam->screen_width; C->height = cam->screen_height;
 }
 
+// K1w: the wavefront pipeline (pt_kernels.hip).  The host drives one iteration per path
+// segment and reads the per-shard counters back each iteration (live paths, traversal queue
+// lengths), so this variant synchronises `stream` internally.
+//
+// Memory: path state is streamed through HBM — 2 x 96 B (ping/pong) + 4 B queue + 16 B sample
+// slot per path.  The batch is sized to the free HBM (288 GB on MI355X: the whole 1080p/256 spp
+// frame, 531 M paths = 112 GB, is ONE batch), halved on allocation failure.
+static const size_t kWfBytesPerPath = 2 * (size_t)kWfPlanes * sizeof(float4) + 4 + sizeof(float4);
+
+static int wf_alloc(mi_ctx* c, WfArgs& a, uint32_t spp, uint32_t& s_batch) {
+    uint64_t max_paths = c->wf_max_paths;
+    if (max_paths == 0) {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)8 << 30;
+        // what this context already holds for the pipeline can be reused
+        free_b += c->wf_a_bytes + c->wf_b_bytes + c->wf_q_bytes + c->wf_samp_bytes;
+        max_paths = (uint64_t)((double)free_b * 0.6 / (double)kWfBytesPerPath);
+    }
+    if (max_paths > (1ull << 31)) max_paths = 1ull << 31;           // 32-bit path indices
+    uint64_t sb = max_paths / a.npix;
+    if (sb < 1) sb = 1;
+    if (sb > spp) sb = spp;
+    for (;;) {
+        s_batch = (uint32_t)sb;
+        const uint32_t paths = a.npix * s_batch;
+        const uint32_t max_blocks = (paths + kBlock - 1) / kBlock;
+        a.region = ((max_blocks + kWfShards - 1) / kWfShards) * kBlock;     // a shard never receives more than its input blocks hold
+        a.cap = a.region * (uint32_t)kWfShards;
+        const size_t st_bytes = (size_t)kWfPlanes * sizeof(float4) * a.cap;
+        int rc = ensure(&c->d_wf_a, &c->wf_a_bytes, st_bytes);
+        if (rc == MI_OK) rc = ensure(&c->d_wf_b, &c->wf_b_bytes, st_bytes);
+        if (rc == MI_OK) rc = ensure(&c->d_wf_q, &c->wf_q_bytes, (size_t)a.cap * 4);
+        if (rc == MI_OK) rc = ensure(&c->d_wf_samp, &c->wf_samp_bytes, (size_t)paths * sizeof(float4));
+        if (rc == MI_OK) rc = ensure(&c->d_wf_acc, &c->wf_acc_bytes, (size_t)a.npix * sizeof(float4));
+        if (rc == MI_OK) return MI_OK;
+        if (rc != MI_ERR_OOM || sb == 1) return rc;
+        (void)hipGetLastError();
+        sb = (sb + 1) / 2;                                           // back off and retry with half the batch
+    }
+}
+
+static int render_tiles_wavefront(mi_ctx* c, const K1Args& k, const mi_camera_desc* cam, uint32_t padded, bool lds,
+                                  float* d_compact, uint32_t* d_sig, hipStream_t stream) {
+    WfArgs a;
+    memset(&a, 0, sizeof a);
+    a.S = k.S; a.C = k.C; a.R = k.R; a.seed_key = k.seed_key;
+    a.npix = padded * (uint32_t)kTilePixels;
+    const uint32_t spp = cam->aa_sample_count;
+    if (spp > 0xffffu) return fail(MI_ERR_UNSUPPORTED, "wavefront variant: aa_sample_count must be <= 65535");
+    if (cam->path_depth > 0xffffu) return fail(MI_ERR_UNSUPPORTED, "wavefront variant: path_depth must be <= 65535");
+    uint32_t s_batch = 1;
+    int rc = wf_alloc(c, a, spp, s_batch);
+    if (rc != MI_OK) return rc;
+    // counters: [0..S) out_count, [S..2S) trav_count, [2S] trav_head, then in_count [S], in_blkpfx [S+1], trav_pfx [S+1]
+    const size_t S_ = (size_t)kWfShards;
+    uint32_t* cnt = c->d_wf_cnt;
+    a.out_count = cnt; a.trav_count = cnt + S_; a.trav_head = cnt + 2 * S_;
+    uint32_t* d_in_count = cnt + 3 * S_;
+    uint32_t* d_in_pfx = cnt + 4 * S_;
+    a.in_count = d_in_count; a.in_blkpfx = d_in_pfx;
+    uint32_t* d_trav_pfx = cnt + 5 * S_ + 8;
+    a.trav_pfx = d_trav_pfx;
+    a.trav_q = (uint32_t*)c->d_wf_q; a.samp = (float4*)c->d_wf_samp; a.accum = (float4*)c->d_wf_acc;
+    a.out = d_compact; a.sig = d_sig;
+    a.refill_min = 16;
+    if (const char* e = getenv("MI_RT_WF_REFILL")) a.refill_min = (uint32_t)atoi(e);
+    if (a.refill_min < 1) a.refill_min = 1;
+    if (a.refill_min > 64) a.refill_min = 64;
+    a.R.lds_nodes = lds ? (uint32_t)c->S.n_nodes : 0;
+    a.R.lds_tris = lds ? (uint32_t)c->S.n_tris : 0;
+    float4* bufs[2] = { (float4*)c->d_wf_a, (float4*)c->d_wf_b };
+    const uint32_t trav_blocks = (uint32_t)c->n_cus * 6u;
+    std::vector<uint32_t> h(2 * S_), hin(2 * S_ + 1), htp(S_ + 1);
+
+    // per-kernel timing: one event pair per launch, summed after the frame
+    size_t ev_used = 0;
+    std::vector<int> ev_kind;
+    auto stamp = [&](int kind) -> int {      // kind: 0 wf_main, 1 wf_trav, 2 wf_reduce; call before AND after the launch
+        if (ev_used == c->wf_ev.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return MI_ERR_HIP; c->wf_ev.push_back(e); }
+        if (hipEventRecord(c->wf_ev[ev_used++], stream) != hipSuccess) return MI_ERR_HIP;
+        ev_kind.push_back(kind);
+        return MI_OK;
+    };
+#define WF_TIMED(kind, call) do { if (stamp(kind) != MI_OK) return fail(MI_ERR_HIP, "event"); HIP_TRY(call); if (stamp(kind) != MI_OK) return fail(MI_ERR_HIP, "event"); } while (0)
+
+    for (uint32_t s0 = 0; s0 < spp; s0 += s_batch) {
+        a.s_base = s0; a.s_count = (s0 + s_batch <= spp) ? s_batch : (spp - s0);
+        int cur = 0;
+        a.iter0 = 1;
+        a.n_in = a.npix * a.s_count;
+        uint32_t n_blocks = (a.n_in + kBlock - 1) / kBlock;
+        for (uint32_t it = 0; it <= cam->path_depth + 1u && n_blocks > 0; it++) {
+            HIP_TRY(hipMemsetAsync(cnt, 0, (2 * S_ + 8) * sizeof(uint32_t), stream));
+            a.st_in = a.iter0 ? nullptr : bufs[cur];
+            a.st_out = bufs[cur ^ 1];
+            a.n_blocks_in = n_blocks;
+            WF_TIMED(0, launch_wf_main(a, n_blocks, d_sig != nullptr, stream));
+            HIP_TRY(hipMemcpyAsync(h.data(), cnt, 2 * S_ * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipStreamSynchronize(stream));
+            uint64_t n_trav = 0, n_live = 0;
+            uint32_t blk = 0, acc = 0;
+            for (size_t s2 = 0; s2 < S_; s2++) {
+                n_live += h[s2];
+                hin[s2] = h[s2];                 // in_count for the next iteration
+                hin[S_ + s2] = blk;              // in_blkpfx
+                blk += (h[s2] + kBlock - 1) / kBlock;
+                htp[s2] = acc; acc += h[S_ + s2];
+            }
+            hin[2 * S_] = blk; htp[S_] = acc; n_trav = acc;
+            if (n_trav > 0) {
+                HIP_TRY(hipMemcpyAsync(d_trav_pfx, htp.data(), (S_ + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+                a.n_trav = (uint32_t)n_trav;
+                uint64_t blocks = (n_trav + kBlock - 1) / kBlock;
+                if (blocks > trav_blocks) blocks = trav_blocks;
+                WF_TIMED(1, launch_wf_trav(a, (uint32_t)blocks, lds, c->lds_bytes, stream));
+            }
+            if (n_live == 0) break;
+            HIP_TRY(hipMemcpyAsync(d_in_count, hin.data(), (2 * S_ + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+            n_blocks = blk;
+            cur ^= 1;
+            a.iter0 = 0;
+        }
+        WF_TIMED(2, launch_wf_reduce(a, s0 == 0, s0 + a.s_count >= spp, stream));
+    }
+#undef WF_TIMED
+    HIP_TRY(hipStreamSynchronize(stream));      // host temporaries (hin, htp) were read by async copies
+    c->wf_ms[0] = c->wf_ms[1] = c->wf_ms[2] = 0.0f; c->wf_ms[3] = (float)(ev_used / 2);
+    for (size_t e = 0; e + 1 < ev_used; e += 2) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, c->wf_ev[e], c->wf_ev[e + 1]) == hipSuccess) c->wf_ms[ev_kind[e]] += ms;
+    }
+    return MI_OK;
+}
+
 static int render_tiles(mi_ctx* c, const mi_camera_desc* cam, const mi_render_opts* o, float* d_compact,
                         uint32_t* d_sig, hipStream_t stream, mi_stats* st) {
     int rc = check_camera(cam);
@@ -498,8 +656,8 @@ static int render_tiles(mi_ctx* c, const mi_camera_desc* cam, const mi_render_op
     a.seed_key = lowbias32(o->seed ^ 0x68e31da4u);
     a.out = d_compact;
     a.sig = (o->want_signature && d_sig) ? d_sig : nullptr;
-    int variant = o->variant == MI_VARIANT_DEFAULT ? MI_VARIANT_VOTED : o->variant;
-    if (variant < MI_VARIANT_SIMPLE || variant > MI_VARIANT_POOLED_DIAG) return fail(MI_ERR_INVALID, "unknown variant %d", o->variant);
+    int variant = o->variant == MI_VARIANT_DEFAULT ? MI_VARIANT_WAVEFRONT : o->variant;
+    if (variant < MI_VARIANT_SIMPLE || variant > MI_VARIANT_WAVEFRONT) return fail(MI_ERR_INVALID, "unknown variant %d", o->variant);
     const bool pooled = variant == MI_VARIANT_POOLED || variant == MI_VARIANT_POOLED_DIAG;
     const bool diag = variant == MI_VARIANT_VOTED_DIAG || variant == MI_VARIANT_POOLED_DIAG;
     a.park = nullptr;
@@ -517,7 +675,10 @@ static int render_tiles(mi_ctx* c, const mi_camera_desc* cam, const mi_render_op
         HIP_TRY(hipMemsetAsync(c->d_diag, 0, 16 * sizeof(unsigned long long), stream));
     }
     HIP_TRY(hipEventRecord(c->ev_start, stream));
-    if (pooled)
+    if (variant == MI_VARIANT_WAVEFRONT) {
+        int rcw = render_tiles_wavefront(c, a, cam, padded, lds, d_compact, a.sig, stream);
+        if (rcw != MI_OK) return rcw;
+    } else if (pooled)
         HIP_TRY(launch_megakernel_pooled(a, padded, lds, a.sig != nullptr, diag, c->lds_bytes, stream));
     else if (variant == MI_VARIANT_VOTED || variant == MI_VARIANT_VOTED_DIAG)
         HIP_TRY(launch_megakernel_voted(a, n_blocks, lds, a.sig != nullptr, diag, c->lds_bytes + c->lds_pad, stream));
@@ -574,6 +735,12 @@ extern "C" int mi_last_kernel_ms(mi_ctx* c, float* ms) {
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipEventSynchronize(c->ev_stop));
     HIP_TRY(hipEventElapsedTime(ms, c->ev_start, c->ev_stop));
+    return MI_OK;
+}
+
+extern "C" int mi_last_pipeline_ms(mi_ctx* c, float* out4) {
+    if (!c || !out4) return fail(MI_ERR_INVALID, "mi_last_pipeline_ms: bad argument");
+    for (int i = 0; i < 4; i++) out4[i] = c->wf_ms[i];
     return MI_OK;
 }
 

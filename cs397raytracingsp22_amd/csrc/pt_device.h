@@ -166,4 +166,44 @@ struct K1Args {
     float4* park;               // POOLED kernel: parked path records [block][v][q][thread]
 };
 
+// ---- wavefront pipeline (pt_kernels.hip "K1w") ----
+// Path state streamed through HBM as 6 float4 planes [6][cap] (coalesced 16-byte accesses):
+//   q0 o.xyz d.x | q1 d.yz T.xy | q2 T.z L.xyz | q3 rng.s0 rng.s1 pix sample|depth<<16
+//   q4 sig best.t best.obj best.tri | q5 best.u best.v mesh flags
+constexpr int kWfPlanes = 6;
+// Appends are SHARDED: block b of wf_main appends its survivors to region (b % kWfShards) of
+// st_out with that shard's own counter, so no single address sees more than ~1/256 of the
+// atomics (one word saturates at ~88 atomics/us on gfx950).  A shard's region can never
+// overflow: it receives at most the paths its own input blocks hold.
+constexpr int kWfShards = 256;
+struct WfArgs {
+    DScene  S;
+    DCamera C;
+    DRender R;
+    uint32_t seed_key;
+    float4* st_in;        // state of the live paths of the previous iteration (nullptr at iteration 0)
+    float4* st_out;       // state of the paths that continue, compacted per shard region
+    uint32_t cap;         // plane stride = kWfShards * region
+    uint32_t region;      // slots per shard region (multiple of 256)
+    uint32_t n_in;        // iteration 0: number of new paths (npix * s_count)
+    uint32_t n_blocks_in; // iteration > 0: blocks to run = sum over shards of ceil(count/256)
+    uint32_t iter0;       // 1 = generate camera rays (first iteration of a batch)
+    uint32_t s_base;      // first sample index of this batch
+    uint32_t s_count;     // samples per pixel in this batch
+    uint32_t npix;        // tile-major pixels of this rank = tiles_padded * 1024
+    uint32_t refill_min;  // wf_trav: refill idle lanes only when at least this many are idle (amortises the gather latency)
+    const PT_CONST_AS uint32_t* in_count;    // [kWfShards] live paths per shard region of st_in
+    const PT_CONST_AS uint32_t* in_blkpfx;   // [kWfShards + 1] exclusive prefix of ceil(count/256)
+    uint32_t* out_count;  // [kWfShards] appended to st_out per shard
+    uint32_t* trav_count; // [kWfShards] traversal queue length per shard
+    uint32_t* trav_head;  // [0]: consumption head over the CONCATENATED per-shard queues (wf_trav grabs 256 entries per atomic)
+    const PT_CONST_AS uint32_t* trav_pfx;   // [kWfShards + 1] exclusive prefix of trav_count (host-built)
+    uint32_t n_trav;      // total queue length of this iteration
+    uint32_t* trav_q;     // [cap] per-shard regions of positions (in st_out) whose ray entered a mesh root box
+    float4* samp;         // [s_count][npix] finished samples: L.xyz, signature bits
+    float4* accum;        // [npix] running per-pixel sum (xyz) and signature sum (w bits)
+    float*    out;        // compact framebuffer [tiles_padded][1024][3]
+    uint32_t* sig;        // or nullptr
+};
+
 }  // namespace pt

@@ -1285,6 +1285,290 @@ __global__ __launch_bounds__(kBlock, PT_MIN_WAVES) void pt_megakernel_pooled(K1A
     }
 }
 
+// ---------------------------------------------------------------- K1w: wavefront pipeline
+// Same per-path arithmetic as K1 (same device functions, same order of evaluation, same RNG
+// stream carried in the path state), different execution model: paths live in HBM, one kernel
+// per phase, every launch runs with all lanes live on a COMPACTED list of paths.
+//   wf_main   iteration 0: Camera::generate_rays; later: Scene::shade_ray for the hit found
+//             in the previous iteration.  Then the object list and the mesh root tests for the
+//             new ray.  Paths that end write their radiance to the sample buffer; the others
+//             are appended to st_out (wave-aggregated atomicAdd: one atomic per wave), and the
+//             ones whose ray entered a mesh root box also to the traversal queue.
+//   wf_trav   persistent waves; a lane that has finished its ray pulls the next queue entry
+//             (one atomicAdd per wave and refill round), so the BVH walk runs with full waves
+//             until the queue drains; small register footprint -> high occupancy for the
+//             latency-bound walk.
+//   wf_reduce per pixel, samples added IN ORDER (the reference's summation order), then /n.
+__device__ __forceinline__ uint32_t wf_append(uint32_t* counter, bool want) {
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(want);
+    uint32_t base = 0;
+    if (m != 0ull) {
+        const int leader = __ffsll((long long)m) - 1;
+        const int lane = (int)(threadIdx.x & 63);
+        if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(m));
+        base = (uint32_t)__shfl((int)base, leader);
+    }
+    const unsigned long long lt = (1ull << (threadIdx.x & 63)) - 1ull;
+    return base + (uint32_t)__popcll(m & lt);
+}
+
+__device__ __forceinline__ void wf_pixel_of(const WfArgs& A, uint32_t pix, uint32_t& px, uint32_t& py, bool& in_image) {
+    const uint32_t slot = pix / kTilePixels, in = pix % kTilePixels;
+    const uint32_t tile = slot * (uint32_t)A.R.world + (uint32_t)A.R.rank;
+    px = 0; py = 0; in_image = false;
+    if (tile < A.R.tiles_total) {
+        px = (tile % A.R.tiles_x) * kTile + (in % kTile);
+        py = (tile / A.R.tiles_x) * kTile + (in / kTile);
+        in_image = (px < A.C.width) && (py < A.C.height);
+    }
+}
+
+template <bool LDS, bool SIG>
+__global__ __launch_bounds__(kBlock, PT_MIN_WAVES) void wf_main(WfArgs A) {
+    const DScene& S = A.S;
+    const DCamera& C = A.C;
+    Bvh<LDS> B;            // only the mesh ROOT nodes are read here
+    bvh_bind(B, S, 0);     // roots come from global memory (scalar load: wave-uniform address)
+    const float t_min = 0.001f, t_max = C.max_trace_dist;
+    const uint32_t cap = A.cap;
+    const uint32_t out_shard = blockIdx.x % (uint32_t)kWfShards;
+
+    Path P; Best best;
+    uint32_t pix = 0, sample = 0;
+    bool alive;
+    if (A.iter0) {
+        // ---- Camera::generate_rays (tracing.rs:159-209) ----
+        const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+        const bool valid = i < A.n_in;
+        alive = valid;
+        pix = valid ? (i % A.npix) : 0u;
+        sample = A.s_base + (valid ? (i / A.npix) : 0u);
+        uint32_t px, py; bool in_image;
+        wf_pixel_of(A, pix, px, py, in_image);
+        P.T = mk3(1.0f, 1.0f, 1.0f); P.L = mk3(0.0f, 0.0f, 0.0f); P.depth = 0; P.sig = 0;
+        P.o = P.d = mk3(0.0f, 0.0f, 0.0f); P.rng.s0 = P.rng.s1 = 1u;
+        if (valid && !in_image) {
+            A.samp[(size_t)(sample - A.s_base) * A.npix + pix] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            alive = false;
+        }
+        if (alive) {
+            rng_init(P.rng, A.seed_key, py * C.width + px, sample);
+            generate_ray(C, px, py, sample, P.rng, P.o, P.d);
+        }
+    } else {
+        // which shard region of st_in does this block read?  (binary search in the block prefix)
+        uint32_t lo = 0, hi = (uint32_t)kWfShards;
+        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (A.in_blkpfx[mid] <= blockIdx.x) lo = mid; else hi = mid; }
+        const uint32_t in_shard = lo;
+        const uint32_t local = (blockIdx.x - A.in_blkpfx[in_shard]) * kBlock + threadIdx.x;
+        const bool valid = local < A.in_count[in_shard];
+        alive = valid;
+        const size_t k = (size_t)in_shard * A.region + (valid ? local : 0u);
+        // ---- Scene::shade_ray, one level (tracing.rs:305-321), for the hit of the previous iteration ----
+        const float4 q0 = A.st_in[0 * (size_t)cap + k], q1 = A.st_in[1 * (size_t)cap + k], q2 = A.st_in[2 * (size_t)cap + k];
+        const float4 q3 = A.st_in[3 * (size_t)cap + k], q4 = A.st_in[4 * (size_t)cap + k], q5 = A.st_in[5 * (size_t)cap + k];
+        P.o = mk3(q0.x, q0.y, q0.z); P.d = mk3(q0.w, q1.x, q1.y); P.T = mk3(q1.z, q1.w, q2.x); P.L = mk3(q2.y, q2.z, q2.w);
+        P.rng.s0 = __float_as_uint(q3.x); P.rng.s1 = __float_as_uint(q3.y);
+        pix = __float_as_uint(q3.z);
+        const uint32_t sd = __float_as_uint(q3.w);
+        sample = sd & 0xffffu; P.depth = sd >> 16;
+        P.sig = __float_as_uint(q4.x);
+        best.t = q4.y; best.obj = __float_as_int(q4.z); best.tri = __float_as_int(q4.w); best.u = q5.x; best.v = q5.y;
+        if (alive) {
+            bool end_path;
+            if (best.obj < 0) {
+                end_path = true;
+                if (SIG) P.sig = sig_end_miss(P.sig, P.rng);
+            } else {
+                if (SIG) P.sig = sig_hit(P.sig, best.t, best.obj);
+                Surf s;
+                resolve_hit(S, best, P.o, P.d, s);
+                P.L = mk3(P.L.x + P.T.x * s.emission.x, P.L.y + P.T.y * s.emission.y, P.L.z + P.T.z * s.emission.z);
+                P.depth++;
+                if (P.depth >= C.path_depth) {
+                    end_path = true;
+                    if (SIG) P.sig = sig_end_depth(P.sig);
+                } else {
+                    f3 nd, w;
+                    scatter(s, P.d, P.rng, nd, w);
+                    P.o = s.p; P.d = nd;
+                    P.T = mk3(P.T.x * w.x, P.T.y * w.y, P.T.z * w.z);
+                    end_path = false;
+                }
+            }
+            if (end_path) {
+                A.samp[(size_t)(sample - A.s_base) * A.npix + pix] = make_float4(P.L.x, P.L.y, P.L.z, __uint_as_float(P.sig));
+                alive = false;
+            }
+        }
+    }
+
+    // ---- Scene::intersect_ray for the new ray: object list, then the mesh roots ----
+    int tm = 0;
+    bool enters = false;
+    best.obj = -1; best.t = 0.0f; best.tri = -1; best.u = best.v = 0.0f;
+    if (alive) {
+        intersect_list(S, P.o, P.d, t_min, t_max, P.rng, best);
+        f3 oo, od, inv; int ti, tend, ttb;
+        enters = enter_next_mesh(S, B, tm, P.o, P.d, t_min, t_max, oo, od, inv, ti, tend, ttb);
+    }
+    // ---- compact the survivors into this block's shard region (one atomic per wave) ----
+    const size_t pos = (size_t)out_shard * A.region + wf_append(&A.out_count[out_shard], alive);
+    if (alive) {
+        A.st_out[0 * (size_t)cap + pos] = make_float4(P.o.x, P.o.y, P.o.z, P.d.x);
+        A.st_out[1 * (size_t)cap + pos] = make_float4(P.d.y, P.d.z, P.T.x, P.T.y);
+        A.st_out[2 * (size_t)cap + pos] = make_float4(P.T.z, P.L.x, P.L.y, P.L.z);
+        A.st_out[3 * (size_t)cap + pos] = make_float4(__uint_as_float(P.rng.s0), __uint_as_float(P.rng.s1), __uint_as_float(pix),
+                                                      __uint_as_float((sample & 0xffffu) | (P.depth << 16)));
+        A.st_out[4 * (size_t)cap + pos] = make_float4(__uint_as_float(P.sig), best.t, __int_as_float(best.obj), __int_as_float(best.tri));
+        A.st_out[5 * (size_t)cap + pos] = make_float4(best.u, best.v, __int_as_float(tm), 0.0f);
+    }
+    const uint32_t qpos = wf_append(&A.trav_count[out_shard], alive && enters);
+    if (alive && enters) A.trav_q[(size_t)out_shard * A.region + qpos] = (uint32_t)pos;
+}
+
+// persistent BVH walker with per-lane dynamic refill from the sharded queues
+template <bool LDS>
+__global__ __launch_bounds__(kBlock, 6) void wf_trav(WfArgs A) {
+    const DScene& S = A.S;
+    Bvh<LDS> B;
+    if (LDS) {
+        cf4_ptr gn = (cf4_ptr)S.nodes;
+        cf4_ptr gt = (cf4_ptr)S.tris;
+        int nn = (int)A.R.lds_nodes * 2, nt = (int)A.R.lds_tris * 3;
+        for (int k = threadIdx.x; k < nn; k += kBlock) k1_lds[k] = gn[k];
+        for (int k = threadIdx.x; k < nt; k += kBlock) k1_lds[nn + k] = gt[k];
+        __syncthreads();
+    }
+    bvh_bind(B, S, (int)A.R.lds_nodes * 2);
+    const float t_min = 0.001f, t_max = A.C.max_trace_dist;
+    const uint32_t cap = A.cap;
+    const int last_node = S.n_nodes - 1;
+    const uint32_t lane = threadIdx.x & 63;
+
+    // wave-uniform work cursor: a chunk [wnext, wend) of the CONCATENATED queue (virtual indices;
+    // shard s owns [trav_pfx[s], trav_pfx[s+1])).  One atomicAdd per 256 rays.
+    const uint32_t n_q = A.n_trav;
+    uint32_t wnext = 0, wend = 0;
+    bool drained = false;
+    bool have = false;
+    size_t pos = 0;
+    f3 o = mk3(0.0f, 0.0f, 0.0f), d = o, too = o, tod = o, tinv = o;
+    Best best; best.t = 0.0f; best.obj = -1; best.tri = -1; best.u = best.v = 0.0f;
+    int tm = 0, ti = 0, tend = 0, ttb = 0, tbtri = -1;
+    float tbt = 0.0f, tbu = 0.0f, tbv = 0.0f;
+    float4 c0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), c1 = c0;
+
+    while (true) {
+        // ---- refill idle lanes ----
+        unsigned long long need = __builtin_amdgcn_ballot_w64(!have);
+        const uint32_t n_idle = (uint32_t)__popcll(need);
+        if ((n_idle >= A.refill_min || n_idle == 64u) && !drained) {
+            if (wnext == wend) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(&A.trav_head[0], 256u);
+                base = (uint32_t)__shfl((int)base, 0);
+                if (base >= n_q) drained = true;
+                else { wnext = base; wend = min(base + 256u, n_q); }
+            }
+            const uint32_t avail = wend - wnext;
+            const uint32_t rank = (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
+            const bool take = !have && rank < avail;
+            if (take) {
+                const uint32_t vi = wnext + rank;
+                uint32_t lo = 0, hi = (uint32_t)kWfShards;          // which shard's region holds virtual index vi
+                while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (A.trav_pfx[mid] <= vi) lo = mid; else hi = mid; }
+                pos = A.trav_q[(size_t)lo * A.region + (vi - A.trav_pfx[lo])];
+                const float4 q0 = A.st_out[0 * (size_t)cap + pos], q1 = A.st_out[1 * (size_t)cap + pos];
+                const float4 q4 = A.st_out[4 * (size_t)cap + pos], q5 = A.st_out[5 * (size_t)cap + pos];
+                o = mk3(q0.x, q0.y, q0.z); d = mk3(q0.w, q1.x, q1.y);
+                best.t = q4.y; best.obj = __float_as_int(q4.z); best.tri = __float_as_int(q4.w); best.u = q5.x; best.v = q5.y;
+                tm = __float_as_int(q5.z);
+                // the root test of mesh tm passed in wf_main; redo the set-up (same arithmetic)
+                (void)enter_next_mesh(S, B, tm, o, d, t_min, t_max, too, tod, tinv, ti, tend, ttb);
+                tbt = t_max; tbtri = -1; tbu = tbv = 0.0f;
+                B.node(ti, c0, c1);
+                have = true;
+            }
+            wnext += min(avail, n_idle);
+        }
+        if (__builtin_amdgcn_ballot_w64(have) == 0ull) {
+            if (drained) break;
+            continue;
+        }
+
+        // ---- one voted step: a burst of interior nodes or one leaf (same code as the voted K1) ----
+        const int tri = __float_as_int(c1.w);
+        const bool at_leaf = have & (tri >= 0), at_inner = have & (tri < 0);
+        const int n_leaf = __popcll(__builtin_amdgcn_ballot_w64(at_leaf));
+        const int n_inner = __popcll(__builtin_amdgcn_ballot_w64(at_inner));
+        if (n_inner >= n_leaf) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const bool act = have & (ti < tend) & (__float_as_int(c1.w) < 0);
+                const int skip = __float_as_int(c0.w);
+                float4 l0, l1, s0, s1;
+                B.node(act ? min(ti + 1, last_node) : 0, l0, l1);
+                B.node(act ? min(skip, last_node) : 0, s0, s1);
+                const bool hit = slab(mk3(c0.x, c0.y, c0.z), mk3(c1.x, c1.y, c1.z), too, tinv, t_min, tbt);
+                const bool go = act & hit, stay = !act;
+                ti = stay ? ti : (go ? ti + 1 : skip);
+                c0.x = stay ? c0.x : (go ? l0.x : s0.x); c0.y = stay ? c0.y : (go ? l0.y : s0.y);
+                c0.z = stay ? c0.z : (go ? l0.z : s0.z); c0.w = stay ? c0.w : (go ? l0.w : s0.w);
+                c1.x = stay ? c1.x : (go ? l1.x : s1.x); c1.y = stay ? c1.y : (go ? l1.y : s1.y);
+                c1.z = stay ? c1.z : (go ? l1.z : s1.z); c1.w = stay ? c1.w : (go ? l1.w : s1.w);
+            }
+        } else if (at_leaf) {
+            f3 a, e1, e2;
+            B.tri(ttb + tri, a, e1, e2);
+            float t, u, v;
+            bool ok = tri_t(too, tod, a, e1, e2, t_min, tbt, t, u, v);
+            tbt = ok ? t : tbt; tbtri = ok ? tri : tbtri; tbu = ok ? u : tbu; tbv = ok ? v : tbv;
+            ti = ti + 1;
+            B.node(min(ti, last_node), c0, c1);
+        }
+        if (have && ti >= tend) {
+            if (tbtri >= 0) consider(best, tbt, S.meshes[tm].object_index, tbtri, tbu, tbv);
+            tm++;
+            if (enter_next_mesh(S, B, tm, o, d, t_min, t_max, too, tod, tinv, ti, tend, ttb)) {
+                tbt = t_max; tbtri = -1; tbu = tbv = 0.0f;
+                B.node(ti, c0, c1);
+            } else {
+                // StaticMesh results merged: hand the closest hit back to the path
+                float4 q4 = A.st_out[4 * (size_t)cap + pos];
+                q4.y = best.t; q4.z = __int_as_float(best.obj); q4.w = __int_as_float(best.tri);
+                A.st_out[4 * (size_t)cap + pos] = q4;
+                A.st_out[5 * (size_t)cap + pos] = make_float4(best.u, best.v, 0.0f, 0.0f);
+                have = false;
+            }
+        }
+    }
+}
+
+// per-pixel in-order accumulation of one batch of samples (tracing.rs:232-241)
+__global__ __launch_bounds__(256) void wf_reduce(WfArgs A, uint32_t first_batch, uint32_t last_batch) {
+    const uint32_t pix = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pix >= A.npix) return;
+    float4 acc = first_batch ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : A.accum[pix];
+    uint32_t sigsum = __float_as_uint(acc.w);
+    for (uint32_t s = 0; s < A.s_count; s++) {
+        const float4 v = A.samp[(size_t)s * A.npix + pix];
+        acc.x = acc.x + v.x; acc.y = acc.y + v.y; acc.z = acc.z + v.z;      // final_color += shade_ray(..)  :238
+        sigsum += __float_as_uint(v.w);
+    }
+    acc.w = __uint_as_float(sigsum);
+    A.accum[pix] = acc;
+    if (last_batch) {
+        uint32_t px, py; bool in_image;
+        wf_pixel_of(A, pix, px, py, in_image);
+        const float n = (float)A.C.spp;
+        float* o3 = A.out + (size_t)pix * 3;
+        if (in_image) { o3[0] = acc.x / n; o3[1] = acc.y / n; o3[2] = acc.z / n; }       // :241
+        else { o3[0] = 0.0f; o3[1] = 0.0f; o3[2] = 0.0f; }
+        if (A.sig) A.sig[pix] = in_image ? sigsum : 0u;
+    }
+}
+
 // ---------------------------------------------------------------- K3: un-permute
 // gathered[world][tiles_padded][1024][3] -> image[H][W][3].  One thread per pixel.
 __global__ __launch_bounds__(256) void fb_unpermute(const float* __restrict__ gathered, float* __restrict__ image,
@@ -1372,6 +1656,23 @@ hipError_t launch_megakernel_pooled(const K1Args& args, uint32_t tiles_padded, b
 }
 size_t pooled_park_bytes(uint32_t tiles_padded) {
     return (size_t)tiles_padded * (size_t)(kTilePixels / (kBlock * kV)) * kV * kParkQ * kBlock * sizeof(float4);
+}
+
+hipError_t launch_wf_main(const WfArgs& a, uint32_t n_blocks, bool sig, hipStream_t stream) {
+    dim3 grid(n_blocks), block(kBlock);
+    if (sig) hipLaunchKernelGGL((wf_main<false, true>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((wf_main<false, false>), grid, block, 0, stream, a);
+    return hipGetLastError();
+}
+hipError_t launch_wf_trav(const WfArgs& a, uint32_t n_blocks, bool lds, size_t lds_bytes, hipStream_t stream) {
+    dim3 grid(n_blocks), block(kBlock);
+    if (lds) hipLaunchKernelGGL((wf_trav<true>), grid, block, lds_bytes, stream, a);
+    else hipLaunchKernelGGL((wf_trav<false>), grid, block, 0, stream, a);
+    return hipGetLastError();
+}
+hipError_t launch_wf_reduce(const WfArgs& a, bool first_batch, bool last_batch, hipStream_t stream) {
+    hipLaunchKernelGGL(wf_reduce, dim3((a.npix + 255) / 256), dim3(256), 0, stream, a, first_batch ? 1u : 0u, last_batch ? 1u : 0u);
+    return hipGetLastError();
 }
 
 hipError_t launch_unpermute(const float* gathered, float* image, uint32_t width, uint32_t height, uint32_t tiles_x,

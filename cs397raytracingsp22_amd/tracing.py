@@ -120,6 +120,12 @@ class Context:
         pod = cam.to_pod()
         abi.check(self._lib.mi_tonemap_device(self._h, C.byref(pod), d_image_f32, d_image_u8, stream))
 
+    def last_pipeline_ms(self):
+        """Wavefront pipeline of the last render: dict of per-kernel duration sums (ms) and launch count."""
+        out = (C.c_float * 4)()
+        abi.check(self._lib.mi_last_pipeline_ms(self._h, out))
+        return {"wf_main_ms": float(out[0]), "wf_trav_ms": float(out[1]), "wf_reduce_ms": float(out[2]), "launches": int(out[3])}
+
     def last_diag(self):
         """Counters of the last MI_VARIANT_VOTED_DIAG launch as a dict (diagnostic)."""
         out = (C.c_uint64 * 16)()

@@ -175,13 +175,14 @@ typedef struct mi_render_opts {
 } mi_render_opts;
 
 typedef enum mi_variant {
-    MI_VARIANT_DEFAULT    = 0,  /* library picks (currently MI_VARIANT_VOTED)                      */
+    MI_VARIANT_DEFAULT    = 0,  /* library picks (currently MI_VARIANT_WAVEFRONT)                  */
     MI_VARIANT_SIMPLE     = 1,  /* one segment per loop trip, mesh traversal in line               */
     MI_VARIANT_PARKED     = 2,  /* mesh rays parked, traversed together when a __ballot vote says so */
     MI_VARIANT_VOTED      = 3,  /* per-lane state machine; every BVH node step is a __ballot-voted phase */
     MI_VARIANT_VOTED_DIAG = 4,  /* VOTED + per-phase trip / active-lane counters (never timed)      */
     MI_VARIANT_POOLED     = 5,  /* VOTED with two path slots per lane (one parked in L2); experimental, slower */
-    MI_VARIANT_POOLED_DIAG = 6  /* POOLED + counters (never timed)                                  */
+    MI_VARIANT_POOLED_DIAG = 6, /* POOLED + counters (never timed)                                  */
+    MI_VARIANT_WAVEFRONT  = 7   /* path state streamed through HBM, one kernel per phase (K1w); synchronises the stream */
 } mi_variant;
 
 typedef struct mi_stats {
@@ -215,8 +216,9 @@ int  mi_render(mi_ctx* ctx, const mi_camera_desc* cam, const mi_render_opts* opt
                float* out_rgb_f32, uint8_t* out_rgb_u8, uint32_t* out_sig, mi_stats* stats);
 
 /* Multi-GPU building blocks; all pointers are DEVICE pointers on ctx's device and
- * `stream` is a hipStream_t (NULL = default stream).  Nothing is synchronised: work is
- * queued on `stream`.
+ * `stream` is a hipStream_t (NULL = default stream).  Work is queued on `stream`; the
+ * megakernel variants never synchronise, the default wavefront variant drives its per-segment
+ * iterations from the host and synchronises `stream` inside mi_render_tiles_device.
  *
  * mi_render_tiles_device: rank `opts->rank` of `opts->world` renders its tiles
  *   (tile t -> rank t % world, slot t / world) into a compact tile-major buffer
@@ -235,6 +237,10 @@ int  mi_tonemap_device(mi_ctx* ctx, const mi_camera_desc* cam,
 /* Elapsed time of the most recent path-tracing kernel of this ctx (HIP events on its
  * launch stream); synchronises on the stop event. */
 int  mi_last_kernel_ms(mi_ctx* ctx, float* ms);
+
+/* Wavefront pipeline (MI_VARIANT_WAVEFRONT) of the most recent render: out4 = { sum of wf_main
+ * launch durations, of wf_trav, of wf_reduce (ms, HIP events around every launch), launches }. */
+int  mi_last_pipeline_ms(mi_ctx* ctx, float* out4);
 
 /* Counters of the most recent *_DIAG launch (synchronises the device):
  * out16 = { A trips, sum of lanes in A trips, interior-step trips, lanes, leaf-step trips,

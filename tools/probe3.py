@@ -10,7 +10,7 @@ sc = {"cfg2": lambda: scenes.config2(1920, 1080, spp, 10), "cfg1": lambda: scene
       "head": lambda: scenes.head_scene(1920, 1080, spp, 10, textures=scenes.load_asset_textures())}[which]()
 ctx = Context(0)
 ctx.upload(sc.flatten())
-for vname, v in (("simple", 1), ("parked", 2), ("voted", 3), ("pooled", 5)):
+for vname, v in (("voted", 3), ("wavefront", 7)):
     best = 1e30
     for rep in range(2):
         _, _, _, st = ctx.render(sc.camera, seed=1, want_f32=True, want_u8=False, variant=v)
