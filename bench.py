@@ -5,9 +5,9 @@
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the hot path over one frame: K1 (path tracing of this rank's
-tiles) -> the frame's single gather (RCCL over xGMI, N > 1 only) -> K3 un-permute ->
-K4 tone-map on rank 0.  Workload = BASELINE.json configs[1]: Cornell box + Utah teapot
+A "step" is one pass of the hot path over one frame: K1w (the wavefront path-tracing
+pipeline over this rank's tiles: wf_main / wf_trav once per path segment + wf_reduce) -> the
+frame's single gather (RCCL over xGMI, N > 1 only) -> K3 un-permute -> K4 tone-map on rank 0.  Workload = BASELINE.json configs[1]: Cornell box + Utah teapot
 BVH, 1920x1080, 256 spp, path_depth 10, synthetic scene built from the reference's
 primitive types (cs397raytracingsp22_amd/scenes.py).  The SAME frame is rendered at every
 N (tiles sharded over ranks), so scaling is "strong"; `value` = W*H*spp / step time,
@@ -53,28 +53,26 @@ def cpu_baseline(sc, flat):
     host's cores on a bounded sample of the same workload."""
     from oracle import orc_py
     cam = sc.camera
-    threads = orc_py.usable_cores()
+    threads = min(orc_py.usable_cores(), 64)
     o = orc_py.OracleScene(flat)
     W, H = cam.screen_width, cam.screen_height
-    # rows are the parallel unit (tracing.rs:228): sample `rows` rows spread evenly over the
-    # whole image height so the sample sees the same mix of cheap and expensive pixels
-    cal_rows = max(threads, 8)
-    stride = max(1, H // cal_rows)
-    t0 = time.perf_counter()
-    o.render(cam, seed=1, threads=threads, window=(0, stride // 2, W // 8, cal_rows), row_stride=stride,
-             want_u8=False, want_sig=False)
-    cal = (time.perf_counter() - t0) * 8.0 / cal_rows              # seconds per full-width row
-    rows = int(max(threads, min(H, 15.0 / max(cal, 1e-6))))
-    rows = max(threads, (rows // threads) * threads)
-    rows = min(rows, H)
-    stride = max(1, H // rows)
-    n = W * rows * cam.aa_sample_count
-    t0 = time.perf_counter()
-    o.render(cam, seed=1, threads=threads, window=(0, (H - (rows - 1) * stride - 1) // 2, W, rows), row_stride=stride,
-             want_u8=False, want_sig=False)
-    dt = time.perf_counter() - t0
+    # rows are the parallel unit (tracing.rs:228).  Time-boxed: successive sets of `threads` rows,
+    # each set spread evenly over the whole image height (same mix of cheap and expensive pixels),
+    # until ~12 s of CPU work have been done.
+    rows_per_set = max(4 * threads, 32)          # several rows per worker: the dynamic row queue balances them
+    stride = max(1, H // rows_per_set)
+    rows_per_set = min(rows_per_set, H // stride)
+    n, sets, dt = 0, 0, 0.0
+    while dt < 12.0 and sets < stride:
+        t0 = time.perf_counter()
+        o.render(cam, seed=1, threads=threads, window=(0, sets, W, rows_per_set), row_stride=stride,
+                 want_u8=False, want_sig=False)
+        dt += time.perf_counter() - t0
+        n += W * rows_per_set * cam.aa_sample_count
+        sets += 1
+    rows = rows_per_set * sets
     return {"value": n / dt / 1e6, "unit": "Msamples/s", "cores": threads, "kind": "port",
-            "sample": f"{rows} full-width rows (every {stride}th) of the same {W}x{H} frame, all {cam.aa_sample_count} spp: "
+            "sample": f"{rows} full-width rows ({sets} sets of every {stride}th row) of the same {W}x{H} frame, all {cam.aa_sample_count} spp: "
                       f"{n} samples in {dt:.1f} s (plain-C oracle, one task per scanline like rayon, tracing.rs:228)"}
 
 
@@ -135,8 +133,11 @@ def main():
         r.render_frame(seed=1)
     barrier()
     t0 = time.perf_counter()
+    pipe = {"wf_main_ms": 0.0, "wf_trav_ms": 0.0, "wf_reduce_ms": 0.0, "launches": 0}
     for s in range(args.steps):
         r.render_frame(seed=1 + s, time_kernel=True)
+        for k, v in ctx.last_pipeline_ms().items():
+            pipe[k] += v
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -155,9 +156,12 @@ def main():
 
     if rank == 0:
         b_sample, segs = algorithmic_bytes_per_sample(cfgname, cam.aa_sample_count)
-        # dominant kernel = K1 pt_megakernel; one launch traces this rank's share of the frame
+        # dominant kernel = K1w, the wavefront pipeline: one pipeline pass traces this rank's share of
+        # the frame (kernel_ms = HIP events around the whole pass; per-kernel sums from events around
+        # every launch).  The megakernel variants (--variant 1..6) are a single launch.
         samples_per_launch = samples_per_frame / world
         achieved = b_sample * samples_per_launch / (kernel_ms * 1e-3) / 1e9
+        per_step = {k: (v / args.steps) for k, v in pipe.items()}
         traffic = measured_traffic(cfgname) if world == 1 and not args.spp else None
         out = {
             "metric": "Msamples/sec (=rays/sec) at 1080p Cornell+teapot, 256 spp; 1/2/4/8 GPU",
@@ -170,11 +174,15 @@ def main():
                        "path_depth": cam.path_depth, "parallelism": f"tiles32x32_mod{world}",
                        "caller": "python ctypes over the C ABI (include/mi_rt.h)",
                        "segments_per_sample": segs, "msegments_per_s": value * segs},
-            "roofline": {"bound": "hbm", "kernel": "pt_megakernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "K1w pipeline (wf_main + wf_trav per segment, wf_reduce)" if per_step["launches"] else "pt_megakernel",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel_ms": kernel_ms, "algorithmic_bytes_per_sample": b_sample,
-                         "note": "algorithmic bytes are what traversal dereferences (SURVEY.md §8d); the scene is "
-                                 "SGPR/LDS-resident, so real HBM traffic is the framebuffer only and the kernel is VALU-bound"},
+                         "per_step_ms": {"wf_main": per_step["wf_main_ms"], "wf_trav": per_step["wf_trav_ms"],
+                                         "wf_reduce": per_step["wf_reduce_ms"], "launches": per_step["launches"]},
+                         "note": "algorithmic bytes = what traversal dereferences (SURVEY.md §8d): object list and BVH are "
+                                 "SGPR/LDS-resident; `traffic` = PMC-measured HBM bytes per pipeline pass, i.e. the path "
+                                 "state streamed between the phase kernels plus the framebuffer"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sc, flat)
