@@ -35,6 +35,9 @@
 
 #pragma clang fp contract(off)
 
+#ifndef PT_TRAV_WAVES
+#define PT_TRAV_WAVES 6     // wf_trav: waves per SIMD (LDS admits 6 blocks of 26.8 KB per CU)
+#endif
 #ifndef PT_MIN_WAVES
 #define PT_MIN_WAVES 4      // waves per SIMD the register allocator must leave room for (<= 128 VGPRs)
 #endif
@@ -1366,14 +1369,18 @@ __global__ __launch_bounds__(kBlock, PT_MIN_WAVES) void wf_main(WfArgs A) {
         const size_t k = (size_t)in_shard * A.region + (valid ? local : 0u);
         // ---- Scene::shade_ray, one level (tracing.rs:305-321), for the hit of the previous iteration ----
         const float4 q0 = A.st_in[0 * (size_t)cap + k], q1 = A.st_in[1 * (size_t)cap + k], q2 = A.st_in[2 * (size_t)cap + k];
-        const float4 q3 = A.st_in[3 * (size_t)cap + k], q4 = A.st_in[4 * (size_t)cap + k], q5 = A.st_in[5 * (size_t)cap + k];
+        const float4 q3 = A.st_in[3 * (size_t)cap + k], q4 = A.st_in[4 * (size_t)cap + k];
         P.o = mk3(q0.x, q0.y, q0.z); P.d = mk3(q0.w, q1.x, q1.y); P.T = mk3(q1.z, q1.w, q2.x); P.L = mk3(q2.y, q2.z, q2.w);
         P.rng.s0 = __float_as_uint(q3.x); P.rng.s1 = __float_as_uint(q3.y);
         pix = __float_as_uint(q3.z);
         const uint32_t sd = __float_as_uint(q3.w);
         sample = sd & 0xffffu; P.depth = sd >> 16;
         P.sig = __float_as_uint(q4.x);
-        best.t = q4.y; best.obj = __float_as_int(q4.z); best.tri = __float_as_int(q4.w); best.u = q5.x; best.v = q5.y;
+        best.t = q4.y; best.obj = __float_as_int(q4.z); best.tri = __float_as_int(q4.w); best.u = 0.0f; best.v = 0.0f;
+        if (valid && best.tri >= 0) {       // plane 5 (barycentrics) exists only for mesh hits
+            const float4 q5 = A.st_in[5 * (size_t)cap + k];
+            best.u = q5.x; best.v = q5.y;
+        }
         if (alive) {
             bool end_path;
             if (best.obj < 0) {
@@ -1421,7 +1428,7 @@ __global__ __launch_bounds__(kBlock, PT_MIN_WAVES) void wf_main(WfArgs A) {
         A.st_out[3 * (size_t)cap + pos] = make_float4(__uint_as_float(P.rng.s0), __uint_as_float(P.rng.s1), __uint_as_float(pix),
                                                       __uint_as_float((sample & 0xffffu) | (P.depth << 16)));
         A.st_out[4 * (size_t)cap + pos] = make_float4(__uint_as_float(P.sig), best.t, __int_as_float(best.obj), __int_as_float(best.tri));
-        A.st_out[5 * (size_t)cap + pos] = make_float4(best.u, best.v, __int_as_float(tm), 0.0f);
+        if (enters) A.st_out[5 * (size_t)cap + pos] = make_float4(0.0f, 0.0f, __int_as_float(tm), 0.0f);   // plane 5 only for mesh rays
     }
     const uint32_t qpos = wf_append(&A.trav_count[out_shard], alive && enters);
     if (alive && enters) A.trav_q[(size_t)out_shard * A.region + qpos] = (uint32_t)pos;
@@ -1429,7 +1436,7 @@ __global__ __launch_bounds__(kBlock, PT_MIN_WAVES) void wf_main(WfArgs A) {
 
 // persistent BVH walker with per-lane dynamic refill from the sharded queues
 template <bool LDS>
-__global__ __launch_bounds__(kBlock, 6) void wf_trav(WfArgs A) {
+__global__ __launch_bounds__(kBlock, PT_TRAV_WAVES) void wf_trav(WfArgs A) {
     const DScene& S = A.S;
     Bvh<LDS> B;
     if (LDS) {
@@ -1482,7 +1489,7 @@ __global__ __launch_bounds__(kBlock, 6) void wf_trav(WfArgs A) {
                 const float4 q0 = A.st_out[0 * (size_t)cap + pos], q1 = A.st_out[1 * (size_t)cap + pos];
                 const float4 q4 = A.st_out[4 * (size_t)cap + pos], q5 = A.st_out[5 * (size_t)cap + pos];
                 o = mk3(q0.x, q0.y, q0.z); d = mk3(q0.w, q1.x, q1.y);
-                best.t = q4.y; best.obj = __float_as_int(q4.z); best.tri = __float_as_int(q4.w); best.u = q5.x; best.v = q5.y;
+                best.t = q4.y; best.obj = __float_as_int(q4.z); best.tri = -1; best.u = 0.0f; best.v = 0.0f;
                 tm = __float_as_int(q5.z);
                 // the root test of mesh tm passed in wf_main; redo the set-up (same arithmetic)
                 (void)enter_next_mesh(S, B, tm, o, d, t_min, t_max, too, tod, tinv, ti, tend, ttb);
