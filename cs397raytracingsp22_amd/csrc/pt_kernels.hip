@@ -1419,6 +1419,14 @@ __global__ __launch_bounds__(kBlock, PT_MIN_WAVES) void wf_main(WfArgs A) {
         f3 oo, od, inv; int ti, tend, ttb;
         enters = enter_next_mesh(S, B, tm, P.o, P.d, t_min, t_max, oo, od, inv, ti, tend, ttb);
     }
+    // A ray that hits no object and enters no mesh ends its path at the next shade_ray level
+    // (tracing.rs:306, background = 0).  Do that level now — same operations, same RNG state —
+    // instead of streaming the path through HBM once more just to terminate it.
+    if (alive && best.obj < 0 && !enters) {
+        if (SIG) P.sig = sig_end_miss(P.sig, P.rng);
+        A.samp[(size_t)(sample - A.s_base) * A.npix + pix] = make_float4(P.L.x, P.L.y, P.L.z, __uint_as_float(P.sig));
+        alive = false;
+    }
     // ---- compact the survivors into this block's shard region (one atomic per wave) ----
     const size_t pos = (size_t)out_shard * A.region + wf_append(&A.out_count[out_shard], alive);
     if (alive) {
