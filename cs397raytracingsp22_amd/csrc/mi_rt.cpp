@@ -565,7 +565,7 @@ static int render_tiles_wavefront(mi_ctx* c, const K1Args& k, const mi_camera_de
     a.trav_pfx = d_trav_pfx;
     a.trav_q = (uint32_t*)c->d_wf_q; a.samp = (float4*)c->d_wf_samp; a.accum = (float4*)c->d_wf_acc;
     a.out = d_compact; a.sig = d_sig;
-    a.refill_min = 16;
+    a.refill_min = 32;
     if (const char* e = getenv("MI_RT_WF_REFILL")) a.refill_min = (uint32_t)atoi(e);
     if (a.refill_min < 1) a.refill_min = 1;
     if (a.refill_min > 64) a.refill_min = 64;

@@ -38,6 +38,9 @@
 #ifndef PT_MAIN_WAVES
 #define PT_MAIN_WAVES 4     // wf_main: minimum waves per SIMD the register allocator must allow
 #endif
+#ifndef PT_TRAV_BURST
+#define PT_TRAV_BURST 6     // wf_trav: interior steps per vote (sweep: 2/4/6/8 -> 52.6/46.8/45.8/46.3 ms at refill 32)
+#endif
 #ifndef PT_TRAV_WAVES
 #define PT_TRAV_WAVES 6     // wf_trav: waves per SIMD (LDS admits 6 blocks of 26.8 KB per CU)
 #endif
@@ -1525,7 +1528,7 @@ __global__ __launch_bounds__(kBlock, PT_TRAV_WAVES) void wf_trav(WfArgs A) {
             // dependent node fetch is covered by the other waves, and this form is 20 instructions
             // per step shorter than prefetching both successors and selecting (used in K1).
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
+            for (int j = 0; j < PT_TRAV_BURST; j++) {
                 const bool act = have & (ti < tend) & (__float_as_int(c1.w) < 0);
                 const bool hit = slab(mk3(c0.x, c0.y, c0.z), mk3(c1.x, c1.y, c1.z), too, tinv, t_min, tbt);
                 const int nxt = hit ? ti + 1 : __float_as_int(c0.w);
