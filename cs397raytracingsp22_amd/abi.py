@@ -103,7 +103,7 @@ class mi_stats(C.Structure):
 EXPORTS = [
     "mi_ctx_create", "mi_ctx_destroy", "mi_scene_upload", "mi_render", "mi_compact_size",
     "mi_render_tiles_device", "mi_unpermute_device", "mi_tonemap_device", "mi_last_kernel_ms",
-    "mi_last_pipeline_ms", "mi_last_diag", "mi_last_error", "mi_abi_version",
+    "mi_reserve", "mi_last_pipeline_ms", "mi_last_diag", "mi_last_error", "mi_abi_version",
 ]
 
 _lib = None
@@ -154,6 +154,8 @@ def load() -> C.CDLL:
     lib.mi_tonemap_device.restype = C.c_int
     lib.mi_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     lib.mi_last_kernel_ms.restype = C.c_int
+    lib.mi_reserve.argtypes = [vp, C.POINTER(mi_camera_desc), C.c_int32]
+    lib.mi_reserve.restype = C.c_int
     lib.mi_last_pipeline_ms.argtypes = [vp, C.POINTER(C.c_float)]
     lib.mi_last_pipeline_ms.restype = C.c_int
     lib.mi_last_diag.argtypes = [vp, C.POINTER(C.c_uint64)]

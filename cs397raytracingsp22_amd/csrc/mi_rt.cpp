@@ -738,6 +738,21 @@ extern "C" int mi_last_kernel_ms(mi_ctx* c, float* ms) {
     return MI_OK;
 }
 
+extern "C" int mi_reserve(mi_ctx* c, const mi_camera_desc* cam, int32_t world) {
+    if (!c) return fail(MI_ERR_INVALID, "ctx is NULL");
+    int rc = check_camera(cam);
+    if (rc != MI_OK) return rc;
+    if (world < 1) return fail(MI_ERR_INVALID, "bad world");
+    HIP_TRY(hipSetDevice(c->device));
+    uint32_t tx, ty, total, padded;
+    tile_counts(cam, world, &tx, &ty, &total, &padded);
+    WfArgs a;
+    memset(&a, 0, sizeof a);
+    a.npix = padded * (uint32_t)kTilePixels;
+    uint32_t s_batch = 1;
+    return wf_alloc(c, a, cam->aa_sample_count, s_batch);
+}
+
 extern "C" int mi_last_pipeline_ms(mi_ctx* c, float* out4) {
     if (!c || !out4) return fail(MI_ERR_INVALID, "mi_last_pipeline_ms: bad argument");
     for (int i = 0; i < 4; i++) out4[i] = c->wf_ms[i];

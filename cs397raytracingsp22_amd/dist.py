@@ -91,6 +91,7 @@ class TiledRenderer:
             self.image = torch.empty((H, W, 3), dtype=torch.float32, device=self.device)
             self.u8 = torch.empty((H, W, 3), dtype=torch.uint8, device=self.device)
         self.kernel_ms = []
+        ctx.reserve(camera, world)          # HBM for the wavefront path state: allocated here, not in the first frame
 
     def render_frame(self, seed: int = 1, time_kernel: bool = False):
         torch = self.torch

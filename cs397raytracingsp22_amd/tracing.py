@@ -120,6 +120,11 @@ class Context:
         pod = cam.to_pod()
         abi.check(self._lib.mi_tonemap_device(self._h, C.byref(pod), d_image_f32, d_image_u8, stream))
 
+    def reserve(self, cam: Camera, world: int = 1):
+        """Allocate the wavefront pipeline's HBM buffers ahead of the first render (mi_reserve)."""
+        pod = cam.to_pod()
+        abi.check(self._lib.mi_reserve(self._h, C.byref(pod), world))
+
     def last_pipeline_ms(self):
         """Wavefront pipeline of the last render: dict of per-kernel duration sums (ms) and launch count."""
         out = (C.c_float * 4)()

@@ -238,6 +238,11 @@ int  mi_tonemap_device(mi_ctx* ctx, const mi_camera_desc* cam,
  * launch stream); synchronises on the stop event. */
 int  mi_last_kernel_ms(mi_ctx* ctx, float* ms);
 
+/* Size and allocate the wavefront pipeline's HBM buffers (path state, queue, sample slots) for
+ * this camera with the image shared by `world` ranks, so that the first render does not pay the
+ * allocation (about 112 GB for a whole 1080p / 256 spp frame on one GPU).  Optional. */
+int  mi_reserve(mi_ctx* ctx, const mi_camera_desc* cam, int32_t world);
+
 /* Wavefront pipeline (MI_VARIANT_WAVEFRONT) of the most recent render: out4 = { sum of wf_main
  * launch durations, of wf_trav, of wf_reduce (ms, HIP events around every launch), launches }. */
 int  mi_last_pipeline_ms(mi_ctx* ctx, float* out4);
