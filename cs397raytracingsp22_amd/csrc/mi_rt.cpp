@@ -542,18 +542,22 @@ static int wf_alloc(mi_ctx* c, WfArgs& a, uint32_t spp, uint32_t& s_batch) {
     }
 }
 
-static int render_tiles_wavefront(mi_ctx* c, const K1Args& k, const mi_camera_desc* cam, uint32_t padded, bool lds,
-                                  float* d_compact, uint32_t* d_sig, hipStream_t stream) {
-    WfArgs a;
+// sizes and allocates (host-side work: must happen BEFORE the timing start event is recorded)
+static int wf_prepare(mi_ctx* c, const mi_camera_desc* cam, uint32_t padded, WfArgs& a, uint32_t& s_batch) {
     memset(&a, 0, sizeof a);
-    a.S = k.S; a.C = k.C; a.R = k.R; a.seed_key = k.seed_key;
     a.npix = padded * (uint32_t)kTilePixels;
     const uint32_t spp = cam->aa_sample_count;
     if (spp > 0xffffu) return fail(MI_ERR_UNSUPPORTED, "wavefront variant: aa_sample_count must be <= 65535");
     if (cam->path_depth > 0xffffu) return fail(MI_ERR_UNSUPPORTED, "wavefront variant: path_depth must be <= 65535");
-    uint32_t s_batch = 1;
-    int rc = wf_alloc(c, a, spp, s_batch);
-    if (rc != MI_OK) return rc;
+    return wf_alloc(c, a, spp, s_batch);
+}
+
+static int render_tiles_wavefront(mi_ctx* c, const K1Args& k, const mi_camera_desc* cam, WfArgs a, uint32_t s_batch, bool lds,
+                                  float* d_compact, uint32_t* d_sig, hipStream_t stream) {
+    a.S = k.S; a.C = k.C; a.R = k.R; a.seed_key = k.seed_key;
+    const uint32_t spp = cam->aa_sample_count;
+    int rc = MI_OK;
+    (void)rc;
     // counters: [0..S) out_count, [S..2S) trav_count, [2S] trav_head, then in_count [S], in_blkpfx [S+1], trav_pfx [S+1]
     const size_t S_ = (size_t)kWfShards;
     uint32_t* cnt = c->d_wf_cnt;
@@ -674,9 +678,14 @@ static int render_tiles(mi_ctx* c, const mi_camera_desc* cam, const mi_render_op
         a.diag = c->d_diag;
         HIP_TRY(hipMemsetAsync(c->d_diag, 0, 16 * sizeof(unsigned long long), stream));
     }
+    WfArgs wa; uint32_t wf_batch = 1;
+    if (variant == MI_VARIANT_WAVEFRONT) {
+        int rcp = wf_prepare(c, cam, padded, wa, wf_batch);
+        if (rcp != MI_OK) return rcp;
+    }
     HIP_TRY(hipEventRecord(c->ev_start, stream));
     if (variant == MI_VARIANT_WAVEFRONT) {
-        int rcw = render_tiles_wavefront(c, a, cam, padded, lds, d_compact, a.sig, stream);
+        int rcw = render_tiles_wavefront(c, a, cam, wa, wf_batch, lds, d_compact, a.sig, stream);
         if (rcw != MI_OK) return rcw;
     } else if (pooled)
         HIP_TRY(launch_megakernel_pooled(a, padded, lds, a.sig != nullptr, diag, c->lds_bytes, stream));
