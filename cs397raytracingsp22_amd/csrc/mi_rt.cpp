@@ -151,7 +151,7 @@ extern "C" int mi_ctx_create(int device, mi_ctx** out) {
     if (const char* e = getenv("MI_RT_KSTEPS")) c->k_steps = (uint32_t)atoi(e);
     if (const char* e = getenv("MI_RT_WF_PATHS")) c->wf_max_paths = (uint64_t)atoll(e);
     c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    HIP_TRY(hipMalloc((void**)&c->d_wf_cnt, (6 * 256 + 32) * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void**)&c->d_wf_cnt, (9 * 256 + 64) * sizeof(uint32_t)));
     if (const char* e = getenv("MI_RT_LDS_PAD_KB")) c->lds_pad = (uint32_t)atoi(e) * 1024u;   // occupancy experiments
     if (c->vote_t < 1) c->vote_t = 1;
     if (c->k_steps < 1) c->k_steps = 1;
@@ -527,7 +527,9 @@ static int wf_alloc(mi_ctx* c, WfArgs& a, uint32_t spp, uint32_t& s_batch) {
         s_batch = (uint32_t)sb;
         const uint32_t paths = a.npix * s_batch;
         const uint32_t max_blocks = (paths + kBlock - 1) / kBlock;
-        a.region = ((max_blocks + kWfShards - 1) / kWfShards) * kBlock;     // a shard never receives more than its input blocks hold
+        // a shard receives at most the paths of its own input blocks: ceil(n_blocks / shards) blocks, where
+        // n_blocks <= max_blocks + 2 * shards (one partial block per (class, shard) range)
+        a.region = ((max_blocks + kWfShards - 1) / kWfShards + 3) * kBlock;
         a.cap = a.region * (uint32_t)kWfShards;
         const size_t st_bytes = (size_t)kWfPlanes * sizeof(float4) * a.cap;
         int rc = ensure(&c->d_wf_a, &c->wf_a_bytes, st_bytes);
@@ -558,14 +560,15 @@ static int render_tiles_wavefront(mi_ctx* c, const K1Args& k, const mi_camera_de
     const uint32_t spp = cam->aa_sample_count;
     int rc = MI_OK;
     (void)rc;
-    // counters: [0..S) out_count, [S..2S) trav_count, [2S] trav_head, then in_count [S], in_blkpfx [S+1], trav_pfx [S+1]
+    // counters: [0..2S) out_count (class A shards, class B shards), [2S..3S) trav_count, [3S] trav_head,
+    // then in_count [2S], in_blkpfx [2S+1], trav_pfx [S+1]
     const size_t S_ = (size_t)kWfShards;
     uint32_t* cnt = c->d_wf_cnt;
-    a.out_count = cnt; a.trav_count = cnt + S_; a.trav_head = cnt + 2 * S_;
-    uint32_t* d_in_count = cnt + 3 * S_;
-    uint32_t* d_in_pfx = cnt + 4 * S_;
+    a.out_count = cnt; a.trav_count = cnt + 2 * S_; a.trav_head = cnt + 3 * S_;
+    uint32_t* d_in_count = cnt + 3 * S_ + 8;
+    uint32_t* d_in_pfx = d_in_count + 2 * S_;
     a.in_count = d_in_count; a.in_blkpfx = d_in_pfx;
-    uint32_t* d_trav_pfx = cnt + 5 * S_ + 8;
+    uint32_t* d_trav_pfx = d_in_pfx + 2 * S_ + 8;
     a.trav_pfx = d_trav_pfx;
     a.trav_q = (uint32_t*)c->d_wf_q; a.samp = (float4*)c->d_wf_samp; a.accum = (float4*)c->d_wf_acc;
     a.out = d_compact; a.sig = d_sig;
@@ -577,7 +580,7 @@ static int render_tiles_wavefront(mi_ctx* c, const K1Args& k, const mi_camera_de
     a.R.lds_tris = lds ? (uint32_t)c->S.n_tris : 0;
     float4* bufs[2] = { (float4*)c->d_wf_a, (float4*)c->d_wf_b };
     const uint32_t trav_blocks = (uint32_t)c->n_cus * 6u;
-    std::vector<uint32_t> h(2 * S_), hin(2 * S_ + 1), htp(S_ + 1);
+    std::vector<uint32_t> h(3 * S_), hin(4 * S_ + 1), htp(S_ + 1);
 
     // per-kernel timing: one event pair per launch, summed after the frame
     size_t ev_used = 0;
@@ -597,23 +600,24 @@ static int render_tiles_wavefront(mi_ctx* c, const K1Args& k, const mi_camera_de
         a.n_in = a.npix * a.s_count;
         uint32_t n_blocks = (a.n_in + kBlock - 1) / kBlock;
         for (uint32_t it = 0; it <= cam->path_depth + 1u && n_blocks > 0; it++) {
-            HIP_TRY(hipMemsetAsync(cnt, 0, (2 * S_ + 8) * sizeof(uint32_t), stream));
+            HIP_TRY(hipMemsetAsync(cnt, 0, (3 * S_ + 8) * sizeof(uint32_t), stream));
             a.st_in = a.iter0 ? nullptr : bufs[cur];
             a.st_out = bufs[cur ^ 1];
             a.n_blocks_in = n_blocks;
             WF_TIMED(0, launch_wf_main(a, n_blocks, d_sig != nullptr, stream));
-            HIP_TRY(hipMemcpyAsync(h.data(), cnt, 2 * S_ * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipMemcpyAsync(h.data(), cnt, 3 * S_ * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
             HIP_TRY(hipStreamSynchronize(stream));
             uint64_t n_trav = 0, n_live = 0;
             uint32_t blk = 0, acc = 0;
-            for (size_t s2 = 0; s2 < S_; s2++) {
+            for (size_t s2 = 0; s2 < 2 * S_; s2++) {       // class A shards, then class B shards
                 n_live += h[s2];
-                hin[s2] = h[s2];                 // in_count for the next iteration
-                hin[S_ + s2] = blk;              // in_blkpfx
+                hin[s2] = h[s2];                       // in_count for the next iteration
+                hin[2 * S_ + s2] = blk;                // in_blkpfx
                 blk += (h[s2] + kBlock - 1) / kBlock;
-                htp[s2] = acc; acc += h[S_ + s2];
             }
-            hin[2 * S_] = blk; htp[S_] = acc; n_trav = acc;
+            hin[4 * S_] = blk;
+            for (size_t s2 = 0; s2 < S_; s2++) { htp[s2] = acc; acc += h[2 * S_ + s2]; }
+            htp[S_] = acc; n_trav = acc;
             if (n_trav > 0) {
                 HIP_TRY(hipMemcpyAsync(d_trav_pfx, htp.data(), (S_ + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
                 a.n_trav = (uint32_t)n_trav;
@@ -622,7 +626,7 @@ static int render_tiles_wavefront(mi_ctx* c, const K1Args& k, const mi_camera_de
                 WF_TIMED(1, launch_wf_trav(a, (uint32_t)blocks, lds, c->lds_bytes, stream));
             }
             if (n_live == 0) break;
-            HIP_TRY(hipMemcpyAsync(d_in_count, hin.data(), (2 * S_ + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+            HIP_TRY(hipMemcpyAsync(d_in_count, hin.data(), (4 * S_ + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
             n_blocks = blk;
             cur ^= 1;
             a.iter0 = 0;

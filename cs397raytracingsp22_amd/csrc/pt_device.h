@@ -192,9 +192,13 @@ struct WfArgs {
     uint32_t s_count;     // samples per pixel in this batch
     uint32_t npix;        // tile-major pixels of this rank = tiles_padded * 1024
     uint32_t refill_min;  // wf_trav: refill idle lanes only when at least this many are idle (amortises the gather latency)
-    const PT_CONST_AS uint32_t* in_count;    // [kWfShards] live paths per shard region of st_in
-    const PT_CONST_AS uint32_t* in_blkpfx;   // [kWfShards + 1] exclusive prefix of ceil(count/256)
-    uint32_t* out_count;  // [kWfShards] appended to st_out per shard
+    // Every shard region is filled from BOTH ENDS: class A (the next shade is a plain Triangle /
+    // Plane hit: the common, cheap case) grows from the front, class B (sphere hits, rays waiting
+    // for a mesh walk, volumes) from the back; A + B can never exceed the region.  The next pass
+    // runs all A blocks, then all B blocks, so most waves execute one shading branch only.
+    const PT_CONST_AS uint32_t* in_count;    // [2*kWfShards] live paths per (class, shard) of st_in: A shards, then B shards
+    const PT_CONST_AS uint32_t* in_blkpfx;   // [2*kWfShards + 1] exclusive prefix of ceil(count/256)
+    uint32_t* out_count;  // [2*kWfShards] appended to st_out per (class, shard)
     uint32_t* trav_count; // [kWfShards] traversal queue length per shard
     uint32_t* trav_head;  // [0]: consumption head over the CONCATENATED per-shard queues (wf_trav grabs 256 entries per atomic)
     const PT_CONST_AS uint32_t* trav_pfx;   // [kWfShards + 1] exclusive prefix of trav_count (host-built)

@@ -508,7 +508,7 @@ __device__ __forceinline__ void test_object(OP ob, int idx, f3 o, f3 d, float t_
         float dd = dot(d, n);
         if (!(dd >= 0.0f)) {
             float t = fabsf(origin_dist) / fabsf(dd);
-            if (!(t < t_min || t > t_max)) consider(best, t, idx, -1, 0.0f, 0.0f);
+            if (!(t < t_min || t > t_max)) consider(best, t, idx, -1, 0.0f, 0.0f);       // Plane: same class as Triangle
         }
     } else if (kind == OBJ_VOLUME) {                                      // geometry.rs:502-526
         const float F32_MIN = -3.40282347e+38f, F32_MAX = 3.40282347e+38f;
@@ -523,7 +523,7 @@ __device__ __forceinline__ void test_object(OP ob, int idx, f3 o, f3 d, float t_
                 float dist_in_volume = t_end - t_start;
                 float dist_before_scatter = ob->f[5] * pt_logf(gen01(rng));     // :517, f[5] = -1/density
                 if (dist_before_scatter < dist_in_volume)
-                    consider(best, t_start + dist_before_scatter, idx, -1, 0.0f, 0.0f);
+                    consider(best, t_start + dist_before_scatter, idx, -3, 0.0f, 0.0f);          // tag -3: volume hit
             }
         }
     }
@@ -532,10 +532,13 @@ __device__ __forceinline__ void test_object(OP ob, int idx, f3 o, f3 d, float t_
 // Scene::intersect_ray over the non-mesh objects (tracing.rs:330-344) through the
 // kind-grouped list: one tight loop per kind, the record of the next object loaded (scalar
 // load, wave-uniform address) while the current one is tested.
-__device__ __forceinline__ void consider_list(Best& b, bool ok, float t, int obj) {
+// `tag` (< 0) records which list loop produced the hit: -1 Triangle, -2 Sphere (Best.tri >= 0 is
+// reserved for mesh triangles); the wavefront pipeline uses it to class the path for free.
+__device__ __forceinline__ void consider_list(Best& b, bool ok, float t, int obj, int tag) {
     bool take = ok & ((b.obj < 0) | (t < b.t) | ((t == b.t) & (obj < b.obj)));
     b.t = take ? t : b.t;
     b.obj = take ? obj : b.obj;
+    b.tri = take ? tag : b.tri;
 }
 __device__ __forceinline__ void intersect_list(const DScene& S, f3 o, f3 d, float t_min, float t_max, Rng& rng, Best& best) {
     auto L = S.list;
@@ -549,14 +552,14 @@ __device__ __forceinline__ void intersect_list(const DScene& S, f3 o, f3 d, floa
             float t0, u0, v0, t1, u1, v1;
             bool ok0 = tri_t(o, d, ld3(r0->f), ld3(r0->f + 3), ld3(r0->f + 6), t_min, t_max, t0, u0, v0);
             bool ok1 = tri_t(o, d, ld3(r1->f), ld3(r1->f + 3), ld3(r1->f + 6), t_min, t_max, t1, u1, v1);
-            consider_list(best, ok0, t0, r0->index);
-            consider_list(best, ok1, t1, r1->index);
+            consider_list(best, ok0, t0, r0->index, -1);
+            consider_list(best, ok1, t1, r1->index, -1);
         }
         for (; k < end; k++) {
             auto r0 = &L[k];
             float t0, u0, v0;
             bool ok0 = tri_t(o, d, ld3(r0->f), ld3(r0->f + 3), ld3(r0->f + 6), t_min, t_max, t0, u0, v0);
-            consider_list(best, ok0, t0, r0->index);
+            consider_list(best, ok0, t0, r0->index, -1);
         }
     }
     {   // Sphere::intersect_ray geometry.rs:395-413
@@ -565,7 +568,7 @@ __device__ __forceinline__ void intersect_list(const DScene& S, f3 o, f3 d, floa
             auto ob = &L[k];
             float t;
             bool ok = sphere_t(o, d, ld3(ob->f), ob->f[4], t_min, t_max, t);
-            consider_list(best, ok, t, ob->index);
+            consider_list(best, ok, t, ob->index, -2);
         }
     }
     {   // Plane (geometry.rs:474-489) and ConvexVolume (geometry.rs:502-526): rare kinds, generic code
@@ -1365,14 +1368,17 @@ __global__ __launch_bounds__(kBlock, PT_MAIN_WAVES) void wf_main(WfArgs A) {
             generate_ray(C, px, py, sample, P.rng, P.o, P.d);
         }
     } else {
-        // which shard region of st_in does this block read?  (binary search in the block prefix)
-        uint32_t lo = 0, hi = (uint32_t)kWfShards;
+        // which (class, shard) range of st_in does this block read?  (binary search in the block prefix:
+        // entries 0..S-1 = class A of each shard, S..2S-1 = class B)
+        uint32_t lo = 0, hi = 2u * (uint32_t)kWfShards;
         while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (A.in_blkpfx[mid] <= blockIdx.x) lo = mid; else hi = mid; }
-        const uint32_t in_shard = lo;
-        const uint32_t local = (blockIdx.x - A.in_blkpfx[in_shard]) * kBlock + threadIdx.x;
-        const bool valid = local < A.in_count[in_shard];
+        const bool cls_b = lo >= (uint32_t)kWfShards;
+        const uint32_t in_shard = cls_b ? lo - (uint32_t)kWfShards : lo;
+        const uint32_t local = (blockIdx.x - A.in_blkpfx[lo]) * kBlock + threadIdx.x;
+        const bool valid = local < A.in_count[lo];
         alive = valid;
-        const size_t k = (size_t)in_shard * A.region + (valid ? local : 0u);
+        const uint32_t lv = valid ? local : 0u;
+        const size_t k = (size_t)in_shard * A.region + (cls_b ? (A.region - 1u - lv) : lv);     // class B grows from the back
         // ---- Scene::shade_ray, one level (tracing.rs:305-321), for the hit of the previous iteration ----
         const float4 q0 = A.st_in[0 * (size_t)cap + k], q1 = A.st_in[1 * (size_t)cap + k], q2 = A.st_in[2 * (size_t)cap + k];
         const float4 q3 = A.st_in[3 * (size_t)cap + k], q4 = A.st_in[4 * (size_t)cap + k];
@@ -1433,8 +1439,13 @@ __global__ __launch_bounds__(kBlock, PT_MAIN_WAVES) void wf_main(WfArgs A) {
         A.samp[(size_t)(sample - A.s_base) * A.npix + pix] = make_float4(P.L.x, P.L.y, P.L.z, __uint_as_float(P.sig));
         alive = false;
     }
-    // ---- compact the survivors into this block's shard region (one atomic per wave) ----
-    const size_t pos = (size_t)out_shard * A.region + wf_append(&A.out_count[out_shard], alive);
+    // ---- compact the survivors into this block's shard region, class A from the front, class B
+    //      from the back (one atomic per wave and class) ----
+    const bool cls_a = alive && !enters && (best.tri == -1);       // next shade: plain Triangle / Plane hit
+    const bool cls_b2 = alive && !cls_a;
+    const uint32_t ia = wf_append(&A.out_count[out_shard], cls_a);
+    const uint32_t ib = wf_append(&A.out_count[(uint32_t)kWfShards + out_shard], cls_b2);
+    const size_t pos = (size_t)out_shard * A.region + (cls_a ? ia : (A.region - 1u - ib));
     if (alive) {
         A.st_out[0 * (size_t)cap + pos] = make_float4(P.o.x, P.o.y, P.o.z, P.d.x);
         A.st_out[1 * (size_t)cap + pos] = make_float4(P.d.y, P.d.z, P.T.x, P.T.y);
