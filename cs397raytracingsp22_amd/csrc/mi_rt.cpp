@@ -580,6 +580,9 @@ static int render_tiles_wavefront(mi_ctx* c, const K1Args& k, const mi_camera_de
     a.R.lds_tris = lds ? (uint32_t)c->S.n_tris : 0;
     float4* bufs[2] = { (float4*)c->d_wf_a, (float4*)c->d_wf_b };
     const uint32_t trav_blocks = (uint32_t)c->n_cus * 6u;
+    uint32_t trav_rpl = 1;
+    if (const char* e = getenv("MI_RT_WF_TRAV_RPL")) trav_rpl = (uint32_t)atoi(e);
+    if (trav_rpl < 1) trav_rpl = 1;
     std::vector<uint32_t> h(3 * S_), hin(4 * S_ + 1), htp(S_ + 1);
 
     // per-kernel timing: one event pair per launch, summed after the frame
@@ -621,7 +624,10 @@ static int render_tiles_wavefront(mi_ctx* c, const K1Args& k, const mi_camera_de
             if (n_trav > 0) {
                 HIP_TRY(hipMemcpyAsync(d_trav_pfx, htp.data(), (S_ + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
                 a.n_trav = (uint32_t)n_trav;
-                uint64_t blocks = (n_trav + kBlock - 1) / kBlock;
+                // persistent walkers: enough blocks to fill the chip, but at least `rpl` rays per lane so
+                // that each wave reaches a steady state of refills (matters for small per-rank queues)
+                uint64_t blocks = (n_trav + (uint64_t)kBlock * trav_rpl - 1) / ((uint64_t)kBlock * trav_rpl);
+                if (blocks < 1) blocks = 1;
                 if (blocks > trav_blocks) blocks = trav_blocks;
                 WF_TIMED(1, launch_wf_trav(a, (uint32_t)blocks, lds, c->lds_bytes, stream));
             }
