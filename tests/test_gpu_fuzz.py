@@ -1,0 +1,84 @@
+"""Randomised parity: seeded random scenes built from every reference primitive and material
+kind, rendered by the HIP path (through the C ABI, default variant and the voted megakernel)
+and compared with the oracle — path signatures bit-exact, radiance within the stated tolerance."""
+import numpy as np
+import pytest
+
+from cs397raytracingsp22_amd import (Camera, ConvexVolume, Dielectric, Isotropic, Lambertian, Metal, ParameterizedMaterial,
+                                     Plane, Scene, Sphere, StaticMesh, Texture, Triangle, abi, cgmath, scenes)
+
+pytestmark = pytest.mark.gpu
+
+
+def random_material(rng, allow_emission=True):
+    k = rng.integers(0, 5)
+    col = tuple(float(x) for x in rng.uniform(0.05, 0.95, 3))
+    em = tuple(float(x) for x in rng.uniform(0.0, 3.0, 3)) if (allow_emission and rng.random() < 0.3) else (0.0, 0.0, 0.0)
+    if k == 0:
+        return Lambertian(albedo=col, emission=em)
+    if k == 1:
+        return Metal(albedo=col, emission=em, roughness=float(rng.uniform(0, 0.8)))
+    if k == 2:
+        return Dielectric(idx_of_refraction=float(rng.uniform(1.1, 2.5)))
+    if k == 3:
+        return ParameterizedMaterial(albedo=col, emission=em, roughness=float(rng.uniform(0, 1)), metallic=float(rng.uniform(0, 1)))
+    return Lambertian(albedo=col, emission=em)
+
+
+def random_scene(seed):
+    rng = np.random.default_rng(seed)
+    objs = []
+    for _ in range(rng.integers(2, 6)):
+        objs.append(Sphere(tuple(float(x) for x in rng.uniform(-3, 3, 3) + np.array([0, 2.5, -2])), float(rng.uniform(0.3, 1.2)),
+                           random_material(rng)))
+    for _ in range(rng.integers(2, 7)):
+        p = rng.uniform(-4, 4, (3, 3)) + np.array([0, 2.5, -3])
+        objs.append(Triangle(tuple(map(float, p[0])), tuple(map(float, p[1])), tuple(map(float, p[2])), random_material(rng)))
+    if rng.random() < 0.7:
+        objs.append(Plane((0.0, float(rng.uniform(-0.5, 0.2)), 0.0), (0.0, 1.0, 0.0), random_material(rng, allow_emission=False)))
+    for _ in range(rng.integers(0, 3)):
+        c = tuple(float(x) for x in rng.uniform(-2.5, 2.5, 3) + np.array([0, 2.0, -1]))
+        objs.append(ConvexVolume(Sphere(c, float(rng.uniform(0.5, 1.3)), Dielectric(1.5)),
+                                 Isotropic(albedo=tuple(float(x) for x in rng.uniform(0.2, 1.0, 3))), float(rng.uniform(0.3, 4.0))))
+    for name in rng.permutation(["teapot", "cube", "drone"])[: rng.integers(0, 3)]:
+        tex = [None] * 5
+        mat = random_material(rng) if rng.random() < 0.5 else None
+        if mat is None:
+            size = 16
+            maps = [Texture(rng.integers(0, 256, (size, size, 3), dtype=np.uint8)) for _ in range(5)]
+            tex = [m if rng.random() < 0.7 else None for m in maps]
+            if tex[0] is None:
+                tex[0] = maps[0]
+        scale = {"teapot": 1.5, "cube": 0.8, "drone": 0.005}[name] * float(rng.uniform(0.7, 1.3))
+        xf = cgmath.mul(cgmath.from_translation(tuple(float(x) for x in rng.uniform(-2, 2, 3) + np.array([0, 2, -1]))),
+                        cgmath.from_angle_y(float(rng.uniform(0, 360))), cgmath.from_angle_x(float(rng.uniform(-90, 90))),
+                        cgmath.from_scale(scale))
+        objs.append(StaticMesh(scenes.load_asset_mesh(name), mat, tex, xf))
+    objs.append(Triangle((-6, 9, -6), (6, 9, -6), (0, 9, 6), Lambertian(albedo=(0.5, 0.5, 0.5), emission=(5.0, 5.0, 5.0))))
+    order = rng.permutation(len(objs))
+    objs = [objs[i] for i in order]                       # Scene.objects order matters (ties, volume RNG draws)
+    spp = int(rng.choice([1, 4, 9, 16]))
+    cam = Camera(eyepoint=(float(rng.uniform(-1, 1)), float(rng.uniform(1.5, 3.5)), float(rng.uniform(5, 8))),
+                 view_dir=(0.0, 0.0, -1.0), up=(0.0, 1.0, 0.0), path_depth=int(rng.integers(1, 13)), path_samples=1,
+                 screen_width=int(rng.integers(33, 120)), screen_height=int(rng.integers(20, 90)),
+                 focal_length=float(rng.uniform(0.4, 1.0)), focus_dist=float(rng.uniform(3, 8)),
+                 lens_radius=float(rng.choice([0.0, 0.03, 0.1])), aa_sample_count=spp,
+                 max_trace_dist=float(rng.choice([100.0, 30.0])), gamma=float(rng.choice([2.0, 2.2, 1.0])))
+    return Scene(cam, objs)
+
+
+@pytest.mark.parametrize("seed", list(range(32)))
+def test_random_scene_parity(gpu_ctx, orc, seed):
+    sc = random_scene(1000 + seed)
+    flat = sc.flatten()
+    gpu_ctx.upload(flat)
+    r32, r8, rsig, _ = orc.OracleScene(flat).render(sc.camera, seed=seed)
+    for variant in (abi.MI_VARIANT_DEFAULT, abi.MI_VARIANT_VOTED):
+        f32, u8, sig, _ = gpu_ctx.render(sc.camera, seed=seed, want_sig=True, variant=variant)
+        bad = int((sig != rsig).sum())
+        assert bad == 0, f"seed {seed} variant {variant}: {bad}/{sig.size} pixels took a different path"
+        finite = np.isfinite(r32)
+        assert np.array_equal(np.isfinite(f32), finite)
+        err = np.abs(f32[finite].astype(np.float64) - r32[finite])
+        assert float((err / np.maximum(1.0, np.abs(r32[finite]))).max(initial=0.0)) <= 5e-5
+        assert int(np.abs(u8.astype(int) - r8.astype(int)).max()) <= 1
