@@ -13,7 +13,7 @@ import numpy as np
 from cs397raytracingsp22_amd import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "_build", "liborc.so")
+LIB_PATH = os.environ.get("ORC_LIB") or os.path.join(_HERE, "_build", "liborc.so")   # ORC_LIB: sanitizer build
 
 
 class orc_counters(C.Structure):
