@@ -37,7 +37,7 @@ hipError_t launch_megakernel_pooled(const K1Args& args, uint32_t tiles_padded, b
                                     size_t lds_bytes, hipStream_t stream);
 size_t pooled_park_bytes(uint32_t tiles_padded);
 hipError_t launch_wf_main(const WfArgs& a, uint32_t n_threads, bool sig, hipStream_t stream);
-hipError_t launch_wf_trav(const WfArgs& a, uint32_t n_blocks, bool lds, size_t lds_bytes, hipStream_t stream);
+hipError_t launch_wf_trav(const WfArgs& a, uint32_t n_blocks, int lds_mode, size_t lds_bytes, hipStream_t stream);
 hipError_t launch_wf_reduce(const WfArgs& a, bool first_batch, bool last_batch, hipStream_t stream);
 hipError_t launch_unpermute(const float* gathered, float* image, uint32_t width, uint32_t height, uint32_t tiles_x,
                             uint32_t world, uint32_t tiles_padded, hipStream_t stream);
@@ -576,10 +576,20 @@ static int render_tiles_wavefront(mi_ctx* c, const K1Args& k, const mi_camera_de
     if (const char* e = getenv("MI_RT_WF_REFILL")) a.refill_min = (uint32_t)atoi(e);
     if (a.refill_min < 1) a.refill_min = 1;
     if (a.refill_min > 64) a.refill_min = 64;
-    a.R.lds_nodes = lds ? (uint32_t)c->S.n_nodes : 0;
-    a.R.lds_tris = lds ? (uint32_t)c->S.n_tris : 0;
+    // wf_trav LDS mode: 2 = BVH nodes in LDS, triangles through L1 (default when the nodes fit 64 KB:
+    // teapot 15 KB -> 8 blocks per CU; 122.6 ms vs 126.0 ms for mode 1 on cfg2 1080p/256), 1 = nodes +
+    // triangles (what the megakernels stage), 0 = everything from global memory
+    const size_t node_bytes = (size_t)c->S.n_nodes * 32;
+    int trav_lds_mode = (c->S.n_meshes > 0 && node_bytes <= 64u * 1024u && !getenv("MI_RT_GLOBAL_BVH")) ? 2 : 0;
+    if (const char* e = getenv("MI_RT_WF_TRAV_LDS")) { int m = atoi(e); if (m == 0 || (m == 1 && lds) || (m == 2 && trav_lds_mode == 2)) trav_lds_mode = m; }
+    const size_t trav_lds_bytes = trav_lds_mode == 1 ? c->lds_bytes : (trav_lds_mode == 2 ? node_bytes : 0);
+    a.R.lds_nodes = trav_lds_mode ? (uint32_t)c->S.n_nodes : 0;
+    a.R.lds_tris = trav_lds_mode == 1 ? (uint32_t)c->S.n_tris : 0;
     float4* bufs[2] = { (float4*)c->d_wf_a, (float4*)c->d_wf_b };
-    const uint32_t trav_blocks = (uint32_t)c->n_cus * 6u;
+    uint32_t trav_bpc = 6;                  // resident blocks per CU: bounded by LDS (160 KB) and by 8 waves/SIMD
+    if (trav_lds_mode == 2) { trav_bpc = (uint32_t)((160u * 1024u) / (node_bytes ? node_bytes : 1)); if (trav_bpc > 8) trav_bpc = 8; if (trav_bpc < 2) trav_bpc = 2; }
+    if (const char* e = getenv("MI_RT_WF_TRAV_BPC")) trav_bpc = (uint32_t)atoi(e);
+    const uint32_t trav_blocks = (uint32_t)c->n_cus * trav_bpc;
     uint32_t trav_rpl = 1;
     if (const char* e = getenv("MI_RT_WF_TRAV_RPL")) trav_rpl = (uint32_t)atoi(e);
     if (trav_rpl < 1) trav_rpl = 1;
@@ -629,7 +639,7 @@ static int render_tiles_wavefront(mi_ctx* c, const K1Args& k, const mi_camera_de
                 uint64_t blocks = (n_trav + (uint64_t)kBlock * trav_rpl - 1) / ((uint64_t)kBlock * trav_rpl);
                 if (blocks < 1) blocks = 1;
                 if (blocks > trav_blocks) blocks = trav_blocks;
-                WF_TIMED(1, launch_wf_trav(a, (uint32_t)blocks, lds, c->lds_bytes, stream));
+                WF_TIMED(1, launch_wf_trav(a, (uint32_t)blocks, trav_lds_mode, trav_lds_bytes, stream));
             }
             if (n_live == 0) break;
             HIP_TRY(hipMemcpyAsync(d_in_count, hin.data(), (4 * S_ + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, stream));

@@ -262,32 +262,35 @@ __device__ __forceinline__ bool tri_t(f3 o, f3 d, f3 a, f3 e1, f3 e2, float t_mi
 
 // AABB::intersect_ray geometry.rs:52-79 with 1/d hoisted out of the node loop (the
 // reference recomputes the same 1/d at every box).
+// The reference tests `tmax <= tmin` after every axis.  tmin never decreases and tmax never increases
+// (f32::max/min drop a NaN operand and the start values are not NaN), so a rejection on an earlier axis
+// is still a rejection after the last one: ONE test at the end gives the same decision.
 __device__ __forceinline__ bool slab(f3 bmin, f3 bmax, f3 o, f3 inv_d, float t_min, float t_max) {
     float tmin = t_min, tmax = t_max;
-    bool rej;
     {
         float t0 = (bmin.x - o.x) * inv_d.x, t1 = (bmax.x - o.x) * inv_d.x;
         bool sw = inv_d.x < 0.0f;
         float ta = sw ? t1 : t0, tb = sw ? t0 : t1;
         tmin = fmaxf(ta, tmin); tmax = fminf(tb, tmax);
-        rej = (tmax <= tmin);
     }
     {
         float t0 = (bmin.y - o.y) * inv_d.y, t1 = (bmax.y - o.y) * inv_d.y;
         bool sw = inv_d.y < 0.0f;
         float ta = sw ? t1 : t0, tb = sw ? t0 : t1;
         tmin = fmaxf(ta, tmin); tmax = fminf(tb, tmax);
-        rej = rej | (tmax <= tmin);
     }
     {
         float t0 = (bmin.z - o.z) * inv_d.z, t1 = (bmax.z - o.z) * inv_d.z;
         bool sw = inv_d.z < 0.0f;
         float ta = sw ? t1 : t0, tb = sw ? t0 : t1;
         tmin = fmaxf(ta, tmin); tmax = fminf(tb, tmax);
-        rej = rej | (tmax <= tmin);
     }
-    return !rej;
+    return !(tmax <= tmin);
 }
+
+// (Negative result, round 1: storing nodes axis-paired so that the subtract/multiply become v_pk_add_f32 /
+// v_pk_mul_f32 made wf_trav SLOWER, 43.5 -> 53.3 ms on cfg2 — 74 VGPRs instead of 64 for the aligned pairs,
+// and no issue-rate gain from the packed form on this path.)
 
 // Matrix4 (column-major) transforms, cgmath Transform3 (geometry.rs:304,307,297)
 template <class FP> __device__ __forceinline__ f3 xform_point(FP m, f3 p) {
@@ -329,6 +332,17 @@ template <bool LDS>
 struct Bvh {
     typename BvhPtr<LDS>::type nodes;      // LDS, or constant-AS global
     typename BvhPtr<LDS>::type tris;
+    __device__ __forceinline__ void node(int i, float4& n0, float4& n1) const { n0 = nodes[2 * i]; n1 = nodes[2 * i + 1]; }
+    __device__ __forceinline__ void tri(int i, f3& a, f3& e1, f3& e2) const {
+        float4 t0 = tris[3 * i], t1 = tris[3 * i + 1], t2 = tris[3 * i + 2];
+        a = mk3(t0.x, t0.y, t0.z); e1 = mk3(t1.x, t1.y, t1.z); e2 = mk3(t2.x, t2.y, t2.z);
+    }
+};
+
+// nodes in LDS, triangles through L1/L2 (wf_trav: halves the LDS footprint -> more resident waves)
+struct BvhNodesLds {
+    const float4* nodes;
+    cf4_ptr tris;
     __device__ __forceinline__ void node(int i, float4& n0, float4& n1) const { n0 = nodes[2 * i]; n1 = nodes[2 * i + 1]; }
     __device__ __forceinline__ void tri(int i, f3& a, f3& e1, f3& e2) const {
         float4 t0 = tris[3 * i], t1 = tris[3 * i + 1], t2 = tris[3 * i + 2];
@@ -1460,14 +1474,20 @@ __global__ __launch_bounds__(kBlock, PT_MAIN_WAVES) void wf_main(WfArgs A) {
 }
 
 // persistent BVH walker with per-lane dynamic refill from the sharded queues
-template <bool LDS>
+// LDS: 0 = BVH in global memory, 1 = nodes + triangles in LDS, 2 = nodes in LDS, triangles in global
+template <int LDS> struct TravBvh { typedef Bvh<false> type; };
+template <> struct TravBvh<1> { typedef Bvh<true> type; };
+template <> struct TravBvh<2> { typedef BvhNodesLds type; };
+__device__ __forceinline__ void bvh_bind(BvhNodesLds& B, const DScene& S, int) { B.nodes = k1_lds; B.tris = (cf4_ptr)S.tris; }
+
+template <int LDS>
 __global__ __launch_bounds__(kBlock, PT_TRAV_WAVES) void wf_trav(WfArgs A) {
     const DScene& S = A.S;
-    Bvh<LDS> B;
-    if (LDS) {
+    typename TravBvh<LDS>::type B;
+    if (LDS != 0) {
         cf4_ptr gn = (cf4_ptr)S.nodes;
         cf4_ptr gt = (cf4_ptr)S.tris;
-        int nn = (int)A.R.lds_nodes * 2, nt = (int)A.R.lds_tris * 3;
+        int nn = (int)A.R.lds_nodes * 2, nt = (LDS == 1) ? (int)A.R.lds_tris * 3 : 0;
         for (int k = threadIdx.x; k < nn; k += kBlock) k1_lds[k] = gn[k];
         for (int k = threadIdx.x; k < nt; k += kBlock) k1_lds[nn + k] = gt[k];
         __syncthreads();
@@ -1692,10 +1712,11 @@ hipError_t launch_wf_main(const WfArgs& a, uint32_t n_blocks, bool sig, hipStrea
     else hipLaunchKernelGGL((wf_main<false, false>), grid, block, 0, stream, a);
     return hipGetLastError();
 }
-hipError_t launch_wf_trav(const WfArgs& a, uint32_t n_blocks, bool lds, size_t lds_bytes, hipStream_t stream) {
+hipError_t launch_wf_trav(const WfArgs& a, uint32_t n_blocks, int lds_mode, size_t lds_bytes, hipStream_t stream) {
     dim3 grid(n_blocks), block(kBlock);
-    if (lds) hipLaunchKernelGGL((wf_trav<true>), grid, block, lds_bytes, stream, a);
-    else hipLaunchKernelGGL((wf_trav<false>), grid, block, 0, stream, a);
+    if (lds_mode == 1) hipLaunchKernelGGL((wf_trav<1>), grid, block, lds_bytes, stream, a);
+    else if (lds_mode == 2) hipLaunchKernelGGL((wf_trav<2>), grid, block, lds_bytes, stream, a);
+    else hipLaunchKernelGGL((wf_trav<0>), grid, block, 0, stream, a);
     return hipGetLastError();
 }
 hipError_t launch_wf_reduce(const WfArgs& a, bool first_batch, bool last_batch, hipStream_t stream) {
