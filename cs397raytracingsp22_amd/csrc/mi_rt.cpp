@@ -36,7 +36,7 @@ hipError_t launch_megakernel_voted(const K1Args& args, uint32_t n_blocks, bool l
 hipError_t launch_megakernel_pooled(const K1Args& args, uint32_t tiles_padded, bool lds, bool sig, bool diag,
                                     size_t lds_bytes, hipStream_t stream);
 size_t pooled_park_bytes(uint32_t tiles_padded);
-hipError_t launch_wf_main(const WfArgs& a, uint32_t n_threads, bool sig, hipStream_t stream);
+hipError_t launch_wf_main(const WfArgs& a, uint32_t n_blocks, bool sig, hipStream_t stream);
 hipError_t launch_wf_trav(const WfArgs& a, uint32_t n_blocks, int lds_mode, size_t lds_bytes, hipStream_t stream);
 hipError_t launch_wf_reduce(const WfArgs& a, bool first_batch, bool last_batch, hipStream_t stream);
 hipError_t launch_unpermute(const float* gathered, float* image, uint32_t width, uint32_t height, uint32_t tiles_x,
@@ -572,6 +572,7 @@ static int render_tiles_wavefront(mi_ctx* c, const K1Args& k, const mi_camera_de
     a.trav_pfx = d_trav_pfx;
     a.trav_q = (uint32_t*)c->d_wf_q; a.samp = (float4*)c->d_wf_samp; a.accum = (float4*)c->d_wf_acc;
     a.out = d_compact; a.sig = d_sig;
+    a.diag = nullptr;
     a.refill_min = 32;
     if (const char* e = getenv("MI_RT_WF_REFILL")) a.refill_min = (uint32_t)atoi(e);
     if (a.refill_min < 1) a.refill_min = 1;

@@ -208,6 +208,7 @@ struct WfArgs {
     float4* accum;        // [npix] running per-pixel sum (xyz) and signature sum (w bits)
     float*    out;        // compact framebuffer [tiles_padded][1024][3]
     uint32_t* sig;        // or nullptr
+    unsigned long long* diag;   // developer builds with -DPT_WF_STAMPS: [16] summed s_memtime deltas of sampled wf_main waves
 };
 
 }  // namespace pt

@@ -1359,6 +1359,13 @@ __global__ __launch_bounds__(kBlock, PT_MAIN_WAVES) void wf_main(WfArgs A) {
     const uint32_t cap = A.cap;
     const uint32_t out_shard = blockIdx.x % (uint32_t)kWfShards;
 
+#ifdef PT_WF_STAMPS
+#define WF_STAMP(k) do { __builtin_amdgcn_s_waitcnt(0); stamp[k] = __builtin_amdgcn_s_memtime(); } while (0)
+    unsigned long long stamp[7] = {0, 0, 0, 0, 0, 0, 0};
+    WF_STAMP(0);
+#else
+#define WF_STAMP(k) do { } while (0)
+#endif
     Path P; Best best;
     uint32_t pix = 0, sample = 0;
     bool alive;
@@ -1386,6 +1393,7 @@ __global__ __launch_bounds__(kBlock, PT_MAIN_WAVES) void wf_main(WfArgs A) {
         // entries 0..S-1 = class A of each shard, S..2S-1 = class B)
         uint32_t lo = 0, hi = 2u * (uint32_t)kWfShards;
         while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (A.in_blkpfx[mid] <= blockIdx.x) lo = mid; else hi = mid; }
+        WF_STAMP(1);
         const bool cls_b = lo >= (uint32_t)kWfShards;
         const uint32_t in_shard = cls_b ? lo - (uint32_t)kWfShards : lo;
         const uint32_t local = (blockIdx.x - A.in_blkpfx[lo]) * kBlock + threadIdx.x;
@@ -1407,6 +1415,7 @@ __global__ __launch_bounds__(kBlock, PT_MAIN_WAVES) void wf_main(WfArgs A) {
             const float4 q5 = A.st_in[5 * (size_t)cap + k];
             best.u = q5.x; best.v = q5.y;
         }
+        WF_STAMP(2);
         if (alive) {
             bool end_path;
             if (best.obj < 0) {
@@ -1436,6 +1445,7 @@ __global__ __launch_bounds__(kBlock, PT_MAIN_WAVES) void wf_main(WfArgs A) {
         }
     }
 
+    WF_STAMP(3);
     // ---- Scene::intersect_ray for the new ray: object list, then the mesh roots ----
     int tm = 0;
     bool enters = false;
@@ -1453,12 +1463,30 @@ __global__ __launch_bounds__(kBlock, PT_MAIN_WAVES) void wf_main(WfArgs A) {
         A.samp[(size_t)(sample - A.s_base) * A.npix + pix] = make_float4(P.L.x, P.L.y, P.L.z, __uint_as_float(P.sig));
         alive = false;
     }
+    WF_STAMP(4);
     // ---- compact the survivors into this block's shard region, class A from the front, class B
     //      from the back (one atomic per wave and class) ----
     const bool cls_a = alive && !enters && (best.tri == -1);       // next shade: plain Triangle / Plane hit
     const bool cls_b2 = alive && !cls_a;
-    const uint32_t ia = wf_append(&A.out_count[out_shard], cls_a);
-    const uint32_t ib = wf_append(&A.out_count[(uint32_t)kWfShards + out_shard], cls_b2);
+    // The three wave-aggregated appends (class A, class B, traversal queue) go out as ONE vector atomic
+    // with lanes 0..2 addressing the three counters: one round trip per wave instead of three in a row
+    // (a returning atomic takes ~3k cycles with every CU issuing them; hipcc waits after each one).
+    uint32_t ia, ib, qpos;
+    {
+        const bool want_t = alive && enters;
+        const unsigned long long ma = __builtin_amdgcn_ballot_w64(cls_a), mb = __builtin_amdgcn_ballot_w64(cls_b2),
+                                 mt = __builtin_amdgcn_ballot_w64(want_t);
+        const uint32_t lane = threadIdx.x & 63;
+        uint32_t* ctr = lane == 0 ? &A.out_count[out_shard] : (lane == 1 ? &A.out_count[(uint32_t)kWfShards + out_shard] : &A.trav_count[out_shard]);
+        const uint32_t add = (uint32_t)__popcll(lane == 0 ? ma : (lane == 1 ? mb : mt));
+        uint32_t base = 0;
+        if (lane < 3 && add != 0) base = atomicAdd(ctr, add);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        ia = (uint32_t)__shfl((int)base, 0) + (uint32_t)__popcll(ma & below);
+        ib = (uint32_t)__shfl((int)base, 1) + (uint32_t)__popcll(mb & below);
+        qpos = (uint32_t)__shfl((int)base, 2) + (uint32_t)__popcll(mt & below);
+    }
+    WF_STAMP(5);
     const size_t pos = (size_t)out_shard * A.region + (cls_a ? ia : (A.region - 1u - ib));
     if (alive) {
         A.st_out[0 * (size_t)cap + pos] = make_float4(P.o.x, P.o.y, P.o.z, P.d.x);
@@ -1469,8 +1497,16 @@ __global__ __launch_bounds__(kBlock, PT_MAIN_WAVES) void wf_main(WfArgs A) {
         A.st_out[4 * (size_t)cap + pos] = make_float4(__uint_as_float(P.sig), best.t, __int_as_float(best.obj), __int_as_float(best.tri));
         if (enters) A.st_out[5 * (size_t)cap + pos] = make_float4(0.0f, 0.0f, __int_as_float(tm), 0.0f);   // plane 5 only for mesh rays
     }
-    const uint32_t qpos = wf_append(&A.trav_count[out_shard], alive && enters);
     if (alive && enters) A.trav_q[(size_t)out_shard * A.region + qpos] = (uint32_t)pos;
+#ifdef PT_WF_STAMPS
+    WF_STAMP(6);       // waits for the state stores too
+    if (A.diag && (blockIdx.x & 63u) == 0u && threadIdx.x == 0) {
+        unsigned long long* d = A.diag + (A.iter0 ? 8 : 0);
+        for (int k = 0; k < 6; k++) if (stamp[k + 1] && stamp[k]) atomicAdd(&d[k], stamp[k + 1] - stamp[k]);
+        atomicAdd(&d[6], 1ull);
+        atomicAdd(&d[7], stamp[6] - stamp[0]);
+    }
+#endif
 }
 
 // persistent BVH walker with per-lane dynamic refill from the sharded queues
