@@ -76,7 +76,8 @@ class mi_scene_desc(C.Structure):
                 ("volumes", C.POINTER(mi_volume)), ("n_volumes", C.c_int32),
                 ("meshes", C.POINTER(mi_mesh)), ("n_meshes", C.c_int32),
                 ("materials", C.POINTER(mi_material)), ("n_materials", C.c_int32),
-                ("textures", C.POINTER(mi_texture)), ("n_textures", C.c_int32)]
+                ("textures", C.POINTER(mi_texture)), ("n_textures", C.c_int32),
+                ("point_light_pos", f3), ("ambient", f3)]
 
 
 class mi_camera_desc(C.Structure):

@@ -37,6 +37,7 @@ hipError_t launch_megakernel_pooled(const K1Args& args, uint32_t tiles_padded, b
                                     size_t lds_bytes, hipStream_t stream);
 size_t pooled_park_bytes(uint32_t tiles_padded);
 hipError_t launch_wf_main(const WfArgs& a, uint32_t n_blocks, bool sig, hipStream_t stream);
+hipError_t launch_phong(const K1Args& a, uint32_t n_blocks, bool sig, hipStream_t stream);
 hipError_t launch_wf_trav(const WfArgs& a, uint32_t n_blocks, int lds_mode, size_t lds_bytes, hipStream_t stream);
 hipError_t launch_wf_reduce(const WfArgs& a, bool first_batch, bool last_batch, hipStream_t stream);
 hipError_t launch_unpermute(const float* gathered, float* image, uint32_t width, uint32_t height, uint32_t tiles_x,
@@ -68,6 +69,7 @@ struct h3 { float x, y, z; };
 inline h3 H3(float x, float y, float z) { h3 r = { x, y, z }; return r; }
 inline h3 H3p(const float* p) { return H3(p[0], p[1], p[2]); }
 inline h3 sub(h3 a, h3 b) { return H3(a.x - b.x, a.y - b.y, a.z - b.z); }
+inline h3 add(h3 a, h3 b) { return H3(a.x + b.x, a.y + b.y, a.z + b.z); }
 inline h3 scale(h3 a, float s) { return H3(a.x * s, a.y * s, a.z * s); }
 inline float dot(h3 a, h3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
 inline h3 cross(h3 a, h3 b) { return H3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
@@ -97,6 +99,7 @@ struct mi_ctx {
     uint32_t* d_sigc = nullptr; size_t sigc_bytes = 0;
     uint32_t* d_sigi = nullptr; size_t sigi_bytes = 0;
     unsigned long long* d_diag = nullptr;    // 8 counters of the diagnostic variant
+    float point_light_pos[3] = {0.0f, 1.0f, 5.0f}, ambient[3] = {0.1f, 0.1f, 0.1f};   // Scene fields read by Phong
     void* d_park = nullptr; size_t park_bytes = 0;   // parked path records of the POOLED kernel
     // wavefront pipeline buffers
     void* d_wf_a = nullptr; size_t wf_a_bytes = 0;   // path state ping
@@ -443,6 +446,7 @@ extern "C" int mi_scene_upload(mi_ctx* c, const mi_scene_desc* d) {
     c->S.n_nodes = (int)(nodes.size() / 8);
     c->S.n_tris = (int)(tris.size() / 12);
     c->lds_bytes = (uint32_t)((nodes.size() + tris.size()) * 4);
+    for (int k = 0; k < 3; k++) { c->point_light_pos[k] = d->point_light_pos[k]; c->ambient[k] = d->ambient[k]; }
     c->have_scene = true;
     return MI_OK;
 }
@@ -450,10 +454,10 @@ extern "C" int mi_scene_upload(mi_ctx* c, const mi_scene_desc* d) {
 // ------------------------------------------------------------------ render
 static int check_camera(const mi_camera_desc* cam) {
     if (!cam) return fail(MI_ERR_INVALID, "camera is NULL");
-    if (cam->projection_mode != MI_PROJ_PERSPECTIVE)
-        return fail(MI_ERR_UNSUPPORTED, "CameraProjectionMode::Orthographic is outside the accelerated path (tracing.rs:196,200)");
-    if (cam->shading_mode != MI_SHADE_PATHTRACE)
-        return fail(MI_ERR_UNSUPPORTED, "ShadingMode::Phong (debug shading, tracing.rs:277-297) is outside the accelerated path");
+    if (cam->projection_mode != MI_PROJ_PERSPECTIVE && cam->projection_mode != MI_PROJ_ORTHOGRAPHIC)
+        return fail(MI_ERR_INVALID, "unknown projection_mode %d", cam->projection_mode);
+    if (cam->shading_mode != MI_SHADE_PATHTRACE && cam->shading_mode != MI_SHADE_PHONG)
+        return fail(MI_ERR_INVALID, "unknown shading_mode %d", cam->shading_mode);
     if (cam->path_samples != 1)
         return fail(MI_ERR_UNSUPPORTED, "path_samples must be 1 on the GPU path (every configuration; tracing.rs:370)");
     if (cam->screen_width == 0 || cam->screen_height == 0 || cam->screen_width > 32768 || cam->screen_height > 32768)
@@ -499,6 +503,11 @@ static void make_camera(const mi_camera_desc* cam, DCamera* C) {
     C->zone = (C->spp << __builtin_clz(C->spp)) - 1u;                   // rand 0.8.4 UniformInt::sample_single
     C->path_depth = cam->path_depth;
     C->width = cam->screen_width; C->height = cam->screen_height;
+    C->ortho = cam->projection_mode == MI_PROJ_ORTHOGRAPHIC ? 1u : 0u;
+    // :200,204  rotation * view_dir with cgmath's Matrix3 * Vector3 order: (c0*v.x + c1*v.y) + c2*v.z
+    h3 c2 = H3(-view.x, -view.y, -view.z);
+    h3 od = add(add(scale(c0, view.x), scale(up, view.y)), scale(c2, view.z));
+    C->ortho_dir[0] = od.x; C->ortho_dir[1] = od.y; C->ortho_dir[2] = od.z;
 }
 
 // K1w: the wavefront pipeline (pt_kernels.hip).  The host drives one iteration per path
@@ -670,6 +679,8 @@ static int render_tiles(mi_ctx* c, const mi_camera_desc* cam, const mi_render_op
     K1Args a;
     a.S = c->S;
     make_camera(cam, &a.C);
+    for (int k = 0; k < 3; k++) { a.C.light[k] = c->point_light_pos[k]; a.C.ambient[k] = c->ambient[k]; }
+    const bool phong = cam->shading_mode == MI_SHADE_PHONG;      // debug shader: own kernel, `variant` is ignored
     uint32_t tx, ty, total, padded;
     tile_counts(cam, o->world, &tx, &ty, &total, &padded);
     a.R.seed = o->seed; a.R.rank = o->rank; a.R.world = o->world;
@@ -700,12 +711,14 @@ static int render_tiles(mi_ctx* c, const mi_camera_desc* cam, const mi_render_op
         HIP_TRY(hipMemsetAsync(c->d_diag, 0, 16 * sizeof(unsigned long long), stream));
     }
     WfArgs wa; uint32_t wf_batch = 1;
-    if (variant == MI_VARIANT_WAVEFRONT) {
+    if (variant == MI_VARIANT_WAVEFRONT && !phong) {
         int rcp = wf_prepare(c, cam, padded, wa, wf_batch);
         if (rcp != MI_OK) return rcp;
     }
     HIP_TRY(hipEventRecord(c->ev_start, stream));
-    if (variant == MI_VARIANT_WAVEFRONT) {
+    if (phong)
+        HIP_TRY(launch_phong(a, n_blocks, a.sig != nullptr, stream));
+    else if (variant == MI_VARIANT_WAVEFRONT) {
         int rcw = render_tiles_wavefront(c, a, cam, wa, wf_batch, lds, d_compact, a.sig, stream);
         if (rcw != MI_OK) return rcw;
     } else if (pooled)

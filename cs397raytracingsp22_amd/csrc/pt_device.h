@@ -141,6 +141,13 @@ struct DCamera {
     uint32_t zone;         // rand UniformInt rejection zone for range = spp
     uint32_t path_depth;
     uint32_t width, height;
+    // CameraProjectionMode::Orthographic (tracing.rs:196,200,204): origin = (centre.x, centre.y, 0) in
+    // camera space as it is, direction = rot * view_dir (the constant, rotated once on the host)
+    uint32_t ortho;
+    float ortho_dir[3];
+    // ShadingMode::Phong (tracing.rs:277-297): Scene.point_light_pos / ambient
+    float light[3];
+    float ambient[3];
 };
 
 struct DRender {

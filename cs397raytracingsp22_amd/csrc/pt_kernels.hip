@@ -596,11 +596,11 @@ __device__ __forceinline__ void intersect_list(const DScene& S, f3 o, f3 d, floa
 
 // Material::scatter (materials.rs) for the resolved surface; returns the new direction
 // and the throughput factor dot_term*brdf/pdf of tracing.rs:313-316.
-__device__ __forceinline__ void scatter(const Surf& s, f3 d, Rng& rng, f3& new_d, f3& weight) {
+// Material::scatter proper: new direction, attenuation (`.1` of the reference's tuple), 1/pdf.
+__device__ __forceinline__ void scatter_raw(const Surf& s, f3 d, Rng& rng, f3& new_d, f3& brdf, float& inv_pdf) {
     int kind = s.kind;
     bool diffuse = (kind == MAT_LAMBERTIAN);
-    f3 brdf;
-    float inv_pdf = 1.0f;
+    inv_pdf = 1.0f;
     if (kind == MAT_PARAMETERIZED) {                                     // materials.rs:116-120
         float fr = fresnel(d, s.n, 1.5f);
         float k_s = fr * (1.0f - s.roughness);
@@ -635,6 +635,11 @@ __device__ __forceinline__ void scatter(const Surf& s, f3 d, Rng& rng, f3& new_d
             }
         }
     }
+}
+// scatter + the estimator's weight dot_term * brdf / pdf (tracing.rs:312-316)
+__device__ __forceinline__ void scatter(const Surf& s, f3 d, Rng& rng, f3& new_d, f3& weight) {
+    f3 brdf; float inv_pdf;
+    scatter_raw(s, d, rng, new_d, brdf, inv_pdf);
     // tracing.rs:313
     float dot_term = (mag2(s.n) > 0.0f) ? clampf(fabsf(dot(new_d, s.n)), 0.0f, 1.0f) : 1.0f;
     float wgt = dot_term * inv_pdf;
@@ -654,8 +659,13 @@ __device__ __forceinline__ void generate_ray(const DCamera& C, uint32_t px, uint
                     -C.focal_length);
     f3 focus = normalize(center) * C.focus_dist;                         // :183
     f3 lens = rand_disk_vec(rng) * C.lens_radius;                        // :184
-    o = ld3(C.eye) + m3mul(C.rot, lens);                                 // :197
-    d = m3mul(C.rot, normalize(focus - lens));                           // :201,204
+    if (C.ortho) {                                                       // :196,200 (wave-uniform)
+        o = mk3(center.x, center.y, 0.0f);
+        d = ld3(C.ortho_dir);
+    } else {
+        o = ld3(C.eye) + m3mul(C.rot, lens);                             // :197
+        d = m3mul(C.rot, normalize(focus - lens));                       // :201,204
+    }
 }
 
 // path-signature steps (diagnostic; DESIGN.md "Path signature")
@@ -818,6 +828,99 @@ __global__ __launch_bounds__(kBlock) void pt_megakernel(K1Args A) {
     }
 
     // ---- per-pixel mean (tracing.rs:241); pixels outside the image are written as 0 ----
+    float n = (float)C.spp;
+    float* o3 = A.out + (size_t)out_idx * 3;
+    if (in_image) { o3[0] = accum.x / n; o3[1] = accum.y / n; o3[2] = accum.z / n; }
+    else { o3[0] = 0.0f; o3[1] = 0.0f; o3[2] = 0.0f; }
+    if (SIG && A.sig) A.sig[out_idx] = in_image ? sigsum : 0u;
+}
+
+// ---------------------------------------------------------------- ShadingMode::Phong
+// Scene::phong_shade_ray (tracing.rs:277-297), the reference's debug shader: one primary hit, a point
+// light with a shadow ray, ambient + diffuse*attenuation + specular.  Not a performance path: one lane
+// per pixel, samples in order, BVH walked in line from global memory.
+template <class BVH>
+__device__ __forceinline__ void intersect_scene(const DScene& S, const BVH& B, f3 o, f3 d, float t_min, float t_max,
+                                                Rng& rng, Best& best) {
+    best.obj = -1; best.t = 0.0f; best.tri = -1; best.u = best.v = 0.0f;
+    intersect_list(S, o, d, t_min, t_max, rng, best);
+    for (int m = 0; m < S.n_meshes; m++) {                               // geometry.rs:301-314
+        auto M = &S.meshes[m];
+        f3 oo = xform_point(M->inv_transform, o);
+        f3 od = xform_vector(M->inv_transform, d);
+        float bt, bu, bv; int btri;
+        traverse_mesh(B, M->node_begin, M->node_end, M->tri_begin, oo, od, t_min, t_max, bt, btri, bu, bv);
+        if (btri >= 0) consider(best, bt, M->object_index, btri, bu, bv);
+    }
+}
+
+// x.powf(40.0) (:287) as a fixed sequence of f32 multiplies (libm powf is not reproducible across CPU and GPU)
+__device__ __forceinline__ float pow40(float x) {
+    float x2 = x * x, x4 = x2 * x2, x8 = x4 * x4, x16 = x8 * x8, x32 = x16 * x16;
+    return x32 * x8;
+}
+
+template <bool SIG>
+__global__ __launch_bounds__(kBlock) void pt_phong(K1Args A) {
+    const DScene& S = A.S;
+    const DCamera& C = A.C;
+    Bvh<false> B;
+    bvh_bind(B, S, 0);
+    const uint32_t slot = blockIdx.x / kBlocksPerTile, sub = blockIdx.x % kBlocksPerTile;
+    const uint32_t tile = slot * (uint32_t)A.R.world + (uint32_t)A.R.rank;
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t in_x = wave * 8 + (lane & 7), in_y = sub * 8 + (lane >> 3);
+    const uint32_t out_idx = slot * kTilePixels + in_y * kTile + in_x;
+    uint32_t px = 0, py = 0;
+    bool in_image = false;
+    if (tile < A.R.tiles_total) {
+        px = (tile % A.R.tiles_x) * kTile + in_x;
+        py = (tile / A.R.tiles_x) * kTile + in_y;
+        in_image = (px < C.width) && (py < C.height);
+    }
+    const uint32_t pixel = py * C.width + px;
+    const float t_max = C.max_trace_dist;
+    const f3 light = ld3(C.light), ambient = ld3(C.ambient), eye = ld3(C.eye);
+    f3 accum = mk3(0.0f, 0.0f, 0.0f);
+    uint32_t sigsum = 0;
+    const uint32_t spp = in_image ? C.spp : 0u;
+    for (uint32_t sample = 0; sample < spp; sample++) {
+        Rng rng; f3 o, d;
+        rng_init(rng, A.seed_key, pixel, sample);
+        generate_ray(C, px, py, sample, rng, o, d);
+        uint32_t sig = 0;
+        f3 color = mk3(0.0f, 0.0f, 0.0f);
+        Best best;
+        intersect_scene(S, B, o, d, 0.0f, t_max, rng, best);             // :279
+        if (best.obj < 0) {
+            if (SIG) sig = sig_end_miss(sig, rng);                       // :280 background = 0
+        } else {
+            if (SIG) sig = sig_hit(sig, best.t, best.obj);
+            Surf s;
+            resolve_hit(S, best, o, d, s);
+            f3 to_light = normalize(light - s.p);                        // :283
+            f3 to_camera = normalize(eye - s.p);                         // :284
+            f3 reflected = -to_light + s.n * (2.0f * dot(to_light, s.n));   // :285
+            float diffuse_weight = clampf(dot(s.n, to_light), 0.0f, 1.0f);  // :286
+            float specular_weight = pow40(clampf(dot(to_camera, reflected), 0.0f, 1.0f));   // :287
+            f3 so = s.p + s.n * 0.01f;                                   // :289
+            float shadow_weight = 1.0f;                                  // :290-293
+            Best sb;
+            intersect_scene(S, B, so, to_light, 0.0f, sqrtf(mag2(light - s.p)), rng, sb);
+            if (sb.obj >= 0) {
+                if (SIG) sig = sig_hit(sig, sb.t, sb.obj);
+                Surf ss;
+                resolve_hit(S, sb, so, to_light, ss);                    // the arm's `hit` is the SHADOW hit
+                shadow_weight = (sb.t * sb.t > mag2(light - ss.p)) ? 1.0f : 0.3f;
+            }
+            f3 nd, brdf; float inv_pdf;
+            scatter_raw(s, d, rng, nd, brdf, inv_pdf);                   // :294 `.scatter(&hit, ray).1`
+            f3 sum = (ambient + brdf * diffuse_weight) + mk3(0.4f, 0.4f, 0.4f) * specular_weight;
+            color = sum * shadow_weight;
+        }
+        accum = accum + color;                                           // :235
+        if (SIG) sigsum += sig;
+    }
     float n = (float)C.spp;
     float* o3 = A.out + (size_t)out_idx * 3;
     if (in_image) { o3[0] = accum.x / n; o3[1] = accum.y / n; o3[2] = accum.z / n; }
@@ -1742,6 +1845,12 @@ size_t pooled_park_bytes(uint32_t tiles_padded) {
     return (size_t)tiles_padded * (size_t)(kTilePixels / (kBlock * kV)) * kV * kParkQ * kBlock * sizeof(float4);
 }
 
+hipError_t launch_phong(const K1Args& a, uint32_t n_blocks, bool sig, hipStream_t stream) {
+    dim3 grid(n_blocks), block(kBlock);
+    if (sig) hipLaunchKernelGGL((pt_phong<true>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((pt_phong<false>), grid, block, 0, stream, a);
+    return hipGetLastError();
+}
 hipError_t launch_wf_main(const WfArgs& a, uint32_t n_blocks, bool sig, hipStream_t stream) {
     dim3 grid(n_blocks), block(kBlock);
     if (sig) hipLaunchKernelGGL((wf_main<false, true>), grid, block, 0, stream, a);

@@ -40,14 +40,15 @@ inline void mi_check(int rc) { if (rc != MI_OK) throw std::runtime_error(std::st
 struct Scene {                                         // tracing.rs:213-218
     Camera camera;
     std::vector<IntersectableRef> objects;
-    Vec3 point_light_pos{0.0f, 1.0f, 5.0f};            // Phong only
-    Vec3 ambient{0.1f, 0.1f, 0.1f};                    // Phong only
+    Vec3 point_light_pos{0.0f, 1.0f, 5.0f};            // read by ShadingMode::Phong only (tracing.rs:282,288)
+    Vec3 ambient{0.1f, 0.1f, 0.1f};                    // Phong only (:292)
 
     // Scene::render_to_image (tracing.rs:221-263).  seed: the reference RNG is unseeded; device: HIP ordinal.
     RgbImage render_to_image(uint32_t seed = 1, int device = 0, mi_stats* stats = nullptr, std::vector<float>* linear = nullptr) const {
         SceneBuilder sb;
         for (auto& o : objects) o->flatten(sb);
         mi_scene_desc d = sb.desc();
+        for (int k = 0; k < 3; k++) { d.point_light_pos[k] = point_light_pos[k]; d.ambient[k] = ambient[k]; }
         mi_camera_desc cam = camera.flatten();
         mi_ctx* ctx = nullptr;
         mi_check(mi_ctx_create(device, &ctx));

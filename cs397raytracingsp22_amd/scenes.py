@@ -191,3 +191,17 @@ def head_scene(width=100, height=100, spp=100, depth=10, with_meshes=True, textu
                  path_samples=1, screen_width=width, screen_height=height, focal_length=0.6, focus_dist=5.0,
                  lens_radius=0.0, aa_sample_count=spp, max_trace_dist=100.0, gamma=2.0)
     return Scene(cam, objs)
+
+
+def with_camera(scene, point_light_pos=None, ambient=None, **camera_fields):
+    """Same scene with some Camera fields replaced (projection_mode, shading_mode, ...) and, for
+    ShadingMode::Phong, the Scene's point light and ambient term (tracing.rs:216-217)."""
+    for k, v in camera_fields.items():
+        if not hasattr(scene.camera, k):
+            raise AttributeError(k)
+        setattr(scene.camera, k, v)
+    if point_light_pos is not None:
+        scene.point_light_pos = tuple(point_light_pos)
+    if ambient is not None:
+        scene.ambient = tuple(ambient)
+    return scene

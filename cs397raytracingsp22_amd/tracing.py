@@ -157,14 +157,17 @@ def compact_size(cam: Camera, world: int):
 class Scene:                         # tracing.rs:213-218
     camera: Camera
     objects: List[Intersectable]
-    point_light_pos: tuple = (0.0, 1.0, 5.0)    # Phong only (debug mode, not accelerated)
-    ambient: tuple = (0.1, 0.1, 0.1)            # Phong only
+    point_light_pos: tuple = (0.0, 1.0, 5.0)    # read by ShadingMode::Phong only (tracing.rs:282,288)
+    ambient: tuple = (0.1, 0.1, 0.1)            # Phong only (:292)
 
     def flatten(self) -> FlatScene:
         fb = FlatBuilder()
         for obj in self.objects:
             obj.flatten(fb)
-        return fb.finish()
+        flat = fb.finish()
+        flat.desc.point_light_pos = abi.f3(*[float(v) for v in self.point_light_pos])
+        flat.desc.ambient = abi.f3(*[float(v) for v in self.ambient])
+        return flat
 
     def render_to_image(self, seed: int = 1, device: int = 0) -> np.ndarray:
         """Scene::render_to_image (tracing.rs:221-263): returns the RgbImage bytes [H,W,3] u8."""

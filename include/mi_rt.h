@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define MI_RT_ABI_VERSION 1
+#define MI_RT_ABI_VERSION 2
 
 /* ---- status codes (reference: panics via assert!/expect/unwrap, geometry.rs:149-151) ---- */
 typedef enum mi_status {
@@ -137,12 +137,15 @@ typedef struct mi_scene_desc {
     const mi_mesh*     meshes;     int32_t n_meshes;
     const mi_material* materials;  int32_t n_materials;
     const mi_texture*  textures;   int32_t n_textures;
+    /* Scene.point_light_pos / Scene.ambient (tracing.rs:216-217): read by ShadingMode::Phong only */
+    float              point_light_pos[3];
+    float              ambient[3];
 } mi_scene_desc;
 
 /* ---- Camera (tracing.rs:138-155), field for field ---- */
-#define MI_PROJ_ORTHOGRAPHIC 0    /* CameraProjectionMode::Orthographic — MI_ERR_UNSUPPORTED */
+#define MI_PROJ_ORTHOGRAPHIC 0    /* CameraProjectionMode::Orthographic (tracing.rs:196,200)           */
 #define MI_PROJ_PERSPECTIVE  1
-#define MI_SHADE_PHONG       0    /* ShadingMode::Phong (debug)         — MI_ERR_UNSUPPORTED */
+#define MI_SHADE_PHONG       0    /* ShadingMode::Phong, the debug shader (tracing.rs:277-297); own kernel, ignores `variant` */
 #define MI_SHADE_PATHTRACE   1
 
 typedef struct mi_camera_desc {

@@ -48,6 +48,7 @@ typedef struct orc_mesh {
 } orc_mesh;
 
 struct orc_scene {
+    float point_light_pos[3], ambient[3];              /* tracing.rs:216-217 (Phong only) */
     mi_object*   objects;   int n_objects;
     mi_sphere*   spheres;   int n_spheres;
     mi_triangle* triangles; int n_triangles;

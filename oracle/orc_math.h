@@ -189,4 +189,12 @@ static inline float orc_logf(float x) {
     return r;
 }
 
+/* `x.powf(40.0)` of phong_shade_ray (tracing.rs:286).  libm's powf is not available bit-for-bit on
+ * the GPU, so both sides use this fixed sequence: x^40 = x^32 * x^8 by repeated squaring (six
+ * roundings; within a few ulp of a correctly rounded powf for x in [0,1]). */
+static inline float orc_pow40(float x) {
+    float x2 = x * x, x4 = x2 * x2, x8 = x4 * x4, x16 = x8 * x8, x32 = x16 * x16;
+    return x32 * x8;
+}
+
 #endif /* ORC_MATH_H */

@@ -1,10 +1,9 @@
 /*
  * orc_tracing.c — TEST INFRASTRUCTURE (oracle).  Restates src/util/tracing.rs of the
  * reference: helpers (:54-97), Ray/RayHit (:104-134), Camera::generate_rays (:159-209),
- * Scene::render_to_image (:221-263), background_color (:266-274), shade_ray (:300-324,
- * recursive, as written) and the scene hit loop (:326-346).  Citations are tracing.rs.
- * phong_shade_ray (:277-297, debug) and the orthographic branch (:196,200) are outside
- * the accelerated path and are not restated.
+ * Scene::render_to_image (:221-263), background_color (:266-274), phong_shade_ray (:277-297),
+ * shade_ray (:300-324, recursive, as written) and the scene hit loop (:326-346).
+ * Citations are tracing.rs.
  */
 #include <stdlib.h>
 #include <pthread.h>
@@ -80,8 +79,15 @@ static orc_ray generate_ray(const mi_camera_desc* cam, uint32_t screen_x, uint32
     rotation.c1 = up;
     rotation.c2 = v3_neg(view_dir);
     orc_ray ray;
-    ray.origin = v3_add(v3_from(cam->eyepoint), m3_mul_v3(rotation, lens_origin));       /* :197 */
-    ray.direction = v3_normalize(v3_sub(focus_plane_pixel_center, lens_origin));         /* :201 */
+    if (cam->projection_mode == MI_PROJ_ORTHOGRAPHIC) {
+        /* :196,200 — the origin stays in camera space (eyepoint and rotation are NOT applied) and the
+         * direction is view_dir, which :204 then rotates like any camera-space direction */
+        ray.origin = v3_make(cam_space_pixel_center.x, cam_space_pixel_center.y, 0.0f);
+        ray.direction = view_dir;
+    } else {
+        ray.origin = v3_add(v3_from(cam->eyepoint), m3_mul_v3(rotation, lens_origin));   /* :197 */
+        ray.direction = v3_normalize(v3_sub(focus_plane_pixel_center, lens_origin));     /* :201 */
+    }
     ray.direction = m3_mul_v3(rotation, ray.direction);               /* :204 */
     return ray;
 }
@@ -158,6 +164,38 @@ static v3 shade_ray(const orc_scene* s, const mi_camera_desc* cam, const orc_ray
     return v3_add(orc_material_emission(&hit.material), integral);    /* :321 */
 }
 
+/* ---- Scene::phong_shade_ray :277-297 (ShadingMode::Phong, "usually just used for debugging") ---- */
+static v3 phong_shade_ray(const orc_scene* s, const mi_camera_desc* cam, const orc_ray* ray, orc_path* p) {
+    orc_rayhit hit;
+    if (!orc_scene_intersect_ray(s, ray, 0.0f, cam->max_trace_dist, p, &hit)) {          /* :279 */
+        sig_end_miss(p);
+        return background_color(ray->direction);                      /* :280 */
+    }
+    sig_hit(p, &hit);
+    v3 light = v3_from(s->point_light_pos);
+    v3 to_light = v3_normalize(v3_sub(light, hit.hitpoint));          /* :283 */
+    v3 to_camera = v3_normalize(v3_sub(v3_from(cam->eyepoint), hit.hitpoint));           /* :284 */
+    /* :285  -to_light + 2.0*dot(to_light, hit.normal)*hit.normal */
+    v3 reflected = v3_add(v3_neg(to_light), v3_scale(hit.normal, 2.0f * v3_dot(to_light, hit.normal)));
+    float diffuse_weight = orc_clampf(v3_dot(hit.normal, to_light), 0.0f, 1.0f);         /* :286 */
+    float specular_weight = orc_pow40(orc_clampf(v3_dot(to_camera, reflected), 0.0f, 1.0f));   /* :287 */
+    orc_ray shadow_ray;                                               /* :289 */
+    shadow_ray.origin = v3_add(hit.hitpoint, v3_scale(hit.normal, 0.01f));
+    shadow_ray.direction = to_light;
+    float shadow_weight = 1.0f;                                       /* :290-293 */
+    orc_rayhit sh;
+    if (orc_scene_intersect_ray(s, &shadow_ray, 0.0f, v3_mag(v3_sub(light, hit.hitpoint)), p, &sh)) {
+        sig_hit(p, &sh);
+        /* the arm's `hit` shadows the outer one: both distances are the SHADOW hit's */
+        shadow_weight = (sh.distance * sh.distance > v3_mag2(v3_sub(light, sh.hitpoint))) ? 1.0f : 0.3f;
+    }
+    orc_ray new_ray; v3 brdf_term; float pdf;                         /* :294 `hit.material.scatter(&hit, ray).1` */
+    orc_material_scatter(&hit.material, &hit, ray, p, &new_ray, &brdf_term, &pdf);
+    v3 amb = v3_from(s->ambient);
+    v3 sum = v3_add(v3_add(amb, v3_scale(brdf_term, diffuse_weight)), v3_scale(v3_make(0.4f, 0.4f, 0.4f), specular_weight));
+    return v3_scale(sum, shadow_weight);
+}
+
 /* ---- pixel epilogue :244-256 ---- */
 static void tonemap_pixel(v3 final_color, float gamma, uint8_t* out) {
     float tmp[3] = { final_color.x, final_color.y, final_color.z };   /* :244 */
@@ -183,7 +221,10 @@ static void render_pixel(const orc_scene* s, const mi_camera_desc* cam, uint32_t
         orc_path p; p.cnt = cnt; p.sig = 0;
         orc_rng_init(&p.rng, seed, pixel, i);
         orc_ray ray = generate_ray(cam, x, y, i, &p);                 /* :231 */
-        final_color = v3_add(final_color, shade_ray(s, cam, &ray, 0, &p));   /* :238 */
+        if (cam->shading_mode == MI_SHADE_PHONG)                      /* :234-239 */
+            final_color = v3_add(final_color, phong_shade_ray(s, cam, &ray, &p));
+        else
+            final_color = v3_add(final_color, shade_ray(s, cam, &ray, 0, &p));
         sigsum += p.sig;
         if (cnt) { cnt->samples++; cnt->rng_draws += p.rng.draws; }
     }
@@ -221,7 +262,8 @@ static void* render_worker(void* arg) {
 
 static int check_camera(const mi_camera_desc* cam) {
     if (!cam) return MI_ERR_INVALID;
-    if (cam->projection_mode != MI_PROJ_PERSPECTIVE || cam->shading_mode != MI_SHADE_PATHTRACE) return MI_ERR_UNSUPPORTED;
+    if (cam->projection_mode != MI_PROJ_PERSPECTIVE && cam->projection_mode != MI_PROJ_ORTHOGRAPHIC) return MI_ERR_INVALID;
+    if (cam->shading_mode != MI_SHADE_PATHTRACE && cam->shading_mode != MI_SHADE_PHONG) return MI_ERR_INVALID;
     if (cam->screen_width == 0 || cam->screen_height == 0 || cam->aa_sample_count == 0 || cam->path_samples == 0) return MI_ERR_INVALID;
     uint32_t r = (uint32_t)sqrtf((float)cam->aa_sample_count);
     if (r == 0) return MI_ERR_INVALID;
@@ -278,6 +320,8 @@ static void* dup_mem(const void* p, size_t n) {
 int orc_scene_create(const mi_scene_desc* d, orc_scene** out) {
     if (!d || !out) return MI_ERR_INVALID;
     orc_scene* s = (orc_scene*)calloc(1, sizeof(orc_scene));
+    memcpy(s->point_light_pos, d->point_light_pos, sizeof s->point_light_pos);
+    memcpy(s->ambient, d->ambient, sizeof s->ambient);
     s->n_objects = d->n_objects;     s->objects = (mi_object*)dup_mem(d->objects, sizeof(mi_object) * (size_t)d->n_objects);
     s->n_spheres = d->n_spheres;     s->spheres = (mi_sphere*)dup_mem(d->spheres, sizeof(mi_sphere) * (size_t)d->n_spheres);
     s->n_triangles = d->n_triangles; s->triangles = (mi_triangle*)dup_mem(d->triangles, sizeof(mi_triangle) * (size_t)d->n_triangles);
@@ -365,7 +409,7 @@ int orc_shade(const orc_scene* s, const mi_camera_desc* cam, const float origin[
     int rc = check_camera(cam); if (rc != MI_OK) return rc;
     orc_path p; p.cnt = NULL; p.sig = 0; orc_rng_init(&p.rng, seed, pixel, sample);
     orc_ray ray; ray.origin = v3_from(origin); ray.direction = v3_from(dir);
-    v3 c = shade_ray(s, cam, &ray, 0, &p);
+    v3 c = (cam->shading_mode == MI_SHADE_PHONG) ? phong_shade_ray(s, cam, &ray, &p) : shade_ray(s, cam, &ray, 0, &p);
     out_rgb[0] = c.x; out_rgb[1] = c.y; out_rgb[2] = c.z;
     return MI_OK;
 }

@@ -22,6 +22,7 @@ use std::os::raw::{c_char, c_int, c_void};
     pub triangles: *const mi_triangle, pub n_triangles: i32, pub planes: *const mi_plane, pub n_planes: i32,
     pub volumes: *const mi_volume, pub n_volumes: i32, pub meshes: *const mi_mesh, pub n_meshes: i32,
     pub materials: *const mi_material, pub n_materials: i32, pub textures: *const mi_texture, pub n_textures: i32,
+    pub point_light_pos: [f32; 3], pub ambient: [f32; 3],   // Scene.point_light_pos / ambient (tracing.rs:216-217), Phong only
 }
 #[repr(C)] pub struct mi_camera_desc {
     pub eyepoint: [f32; 3], pub view_dir: [f32; 3], pub up: [f32; 3], pub projection_mode: i32, pub shading_mode: i32,
@@ -61,6 +62,7 @@ impl SceneBuilder {
             meshes: self.meshes.as_ptr(), n_meshes: self.meshes.len() as i32,
             materials: self.materials.as_ptr(), n_materials: self.materials.len() as i32,
             textures: self.textures.as_ptr(), n_textures: self.textures.len() as i32,
+            point_light_pos: [0.0, 1.0, 5.0], ambient: [0.1, 0.1, 0.1],   // caller overwrites from Scene
         }
     }
 }

@@ -18,6 +18,9 @@ CASES = {
     "cfg4_drone_480x270_16spp": lambda: scenes.config4(480, 270, 16, 10, tex_size=256),
     "cfg5_subsurface_480x270_64spp_d50": lambda: scenes.config5(480, 270, 64, 50),
     "head_200x200_16spp": lambda: scenes.head_scene(200, 200, 16, 10, textures=scenes.load_asset_textures()),
+    "cfg2_phong_480x270_16spp": lambda: scenes.with_camera(scenes.config2(480, 270, 16, 10), shading_mode=0,
+                                                           point_light_pos=(0.5, 4.0, 2.5), ambient=(0.05, 0.1, 0.15)),
+    "cfg2_ortho_240x136_16spp": lambda: scenes.with_camera(scenes.config2(240, 136, 16, 10), projection_mode=0),
 }
 
 

@@ -71,3 +71,41 @@ def test_work_counters_equal_the_oracle(gpu_ctx, orc):
     assert d["leaf_lanes"] == cnt["tri_tests"]
     # the oracle counts the root box test of every mesh call; the kernel does it in the A phase
     assert d["slab_tests"] + cnt["mesh_tests"] == cnt["box_tests"]
+
+
+# ---- the rest of the Camera / Scene surface: orthographic projection, Phong shading ----
+def _mode(sc, **kw):
+    for k, v in kw.items():
+        setattr(sc.camera, k, v)
+    return sc
+
+
+@pytest.mark.parametrize("variant", [abi.MI_VARIANT_SIMPLE, abi.MI_VARIANT_VOTED, abi.MI_VARIANT_WAVEFRONT])
+def test_orthographic_projection(gpu_ctx, orc, variant):
+    """tracing.rs:196,200: shared generate_ray, so every kernel variant must agree with the oracle."""
+    compare(gpu_ctx, orc, _mode(scenes.config2(96, 64, 16, 10), projection_mode=abi.MI_PROJ_ORTHOGRAPHIC), variant=variant)
+
+
+def test_orthographic_tilted_camera(gpu_ctx, orc):
+    sc = _mode(scenes.config1(64, 64, 16, 8), projection_mode=abi.MI_PROJ_ORTHOGRAPHIC,
+               view_dir=(0.0, -0.6, -0.8), up=(0.0, 1.0, 0.0))
+    compare(gpu_ctx, orc, sc)
+
+
+@pytest.mark.parametrize("name", ["config1", "config2", "config4", "config5", "head"])
+def test_phong_shading(gpu_ctx, orc, name):
+    """Scene::phong_shade_ray (tracing.rs:277-297): primary hit, shadow ray, scatter() for the attenuation —
+    spheres, triangles, the teapot BVH, textured ParameterizedMaterial lobes, a ConvexVolume that draws
+    random numbers inside both intersect_ray calls."""
+    sc = {"config1": lambda: scenes.config1(96, 96, 16, 8), "config2": lambda: scenes.config2(128, 96, 16, 10),
+          "config4": lambda: scenes.config4(96, 64, 4, 10, tex_size=64), "config5": lambda: scenes.config5(96, 64, 16, 50),
+          "head": lambda: scenes.head_scene(64, 64, 4, 10)}[name]()
+    sc.point_light_pos = (0.5, 4.0, 2.5)
+    sc.ambient = (0.05, 0.1, 0.15)
+    st = compare(gpu_ctx, orc, _mode(sc, shading_mode=abi.MI_SHADE_PHONG))
+    assert st.samples == sc.camera.screen_width * sc.camera.screen_height * sc.camera.aa_sample_count
+
+
+def test_phong_orthographic_ignores_variant(gpu_ctx, orc):
+    sc = _mode(scenes.config2(75, 41, 9, 6), shading_mode=abi.MI_SHADE_PHONG, projection_mode=abi.MI_PROJ_ORTHOGRAPHIC)
+    compare(gpu_ctx, orc, sc, seed=77, variant=abi.MI_VARIANT_VOTED)

@@ -28,6 +28,12 @@ CASES = {
     "cfg5_subsurface_480x270_64spp_d50": (lambda: scenes.config5(480, 270, 64, 50), (190, 150, 96, 64), 1),
     "head_200x200_16spp": (lambda: scenes.head_scene(200, 200, 16, 10, textures=scenes.load_asset_textures()),
                            (20, 60, 160, 120), 1),
+    # the rest of the Camera/Scene surface: ShadingMode::Phong (0) and CameraProjectionMode::Orthographic (0)
+    "cfg2_phong_480x270_16spp": (lambda: scenes.with_camera(scenes.config2(480, 270, 16, 10), shading_mode=0,
+                                                             point_light_pos=(0.5, 4.0, 2.5), ambient=(0.05, 0.1, 0.15)),
+                                 (176, 110, 128, 96), 3),
+    "cfg2_ortho_240x136_16spp": (lambda: scenes.with_camera(scenes.config2(240, 136, 16, 10), projection_mode=0),
+                                 (56, 20, 128, 96), 1),
 }
 
 
