@@ -104,7 +104,7 @@ class mi_stats(C.Structure):
 EXPORTS = [
     "mi_ctx_create", "mi_ctx_destroy", "mi_scene_upload", "mi_render", "mi_compact_size",
     "mi_render_tiles_device", "mi_unpermute_device", "mi_tonemap_device", "mi_last_kernel_ms",
-    "mi_reserve", "mi_last_pipeline_ms", "mi_last_diag", "mi_last_error", "mi_abi_version",
+    "mi_reserve", "mi_render_samples_device", "mi_last_pipeline_ms", "mi_last_diag", "mi_last_error", "mi_abi_version",
 ]
 
 _lib = None
@@ -149,6 +149,9 @@ def load() -> C.CDLL:
     lib.mi_render_tiles_device.argtypes = [vp, C.POINTER(mi_camera_desc), C.POINTER(mi_render_opts),
                                            vp, vp, vp, C.POINTER(mi_stats)]
     lib.mi_render_tiles_device.restype = C.c_int
+    lib.mi_render_samples_device.argtypes = [vp, C.POINTER(mi_camera_desc), C.POINTER(mi_render_opts), C.c_uint32, C.c_uint32,
+                                             vp, vp, vp, vp, C.POINTER(mi_stats)]
+    lib.mi_render_samples_device.restype = C.c_int
     lib.mi_unpermute_device.argtypes = [vp, C.POINTER(mi_camera_desc), C.c_int32, vp, vp, vp]
     lib.mi_unpermute_device.restype = C.c_int
     lib.mi_tonemap_device.argtypes = [vp, C.POINTER(mi_camera_desc), vp, vp, vp]

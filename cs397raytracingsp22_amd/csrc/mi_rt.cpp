@@ -563,8 +563,12 @@ static int wf_prepare(mi_ctx* c, const mi_camera_desc* cam, uint32_t padded, WfA
     return wf_alloc(c, a, spp, s_batch);
 }
 
+// Samples [begin, end) of every pixel, added in order to `accum` (nullptr = the context's own buffer).
+// begin == 0 starts the sums from zero; end == aa_sample_count also writes the per-pixel means.
+struct SampleRange { uint32_t begin, end; float4* accum; };
+
 static int render_tiles_wavefront(mi_ctx* c, const K1Args& k, const mi_camera_desc* cam, WfArgs a, uint32_t s_batch, bool lds,
-                                  float* d_compact, uint32_t* d_sig, hipStream_t stream) {
+                                  float* d_compact, uint32_t* d_sig, SampleRange range, hipStream_t stream) {
     a.S = k.S; a.C = k.C; a.R = k.R; a.seed_key = k.seed_key;
     const uint32_t spp = cam->aa_sample_count;
     int rc = MI_OK;
@@ -579,7 +583,7 @@ static int render_tiles_wavefront(mi_ctx* c, const K1Args& k, const mi_camera_de
     a.in_count = d_in_count; a.in_blkpfx = d_in_pfx;
     uint32_t* d_trav_pfx = d_in_pfx + 2 * S_ + 8;
     a.trav_pfx = d_trav_pfx;
-    a.trav_q = (uint32_t*)c->d_wf_q; a.samp = (float4*)c->d_wf_samp; a.accum = (float4*)c->d_wf_acc;
+    a.trav_q = (uint32_t*)c->d_wf_q; a.samp = (float4*)c->d_wf_samp; a.accum = range.accum ? range.accum : (float4*)c->d_wf_acc;
     a.out = d_compact; a.sig = d_sig;
     a.diag = nullptr;
     a.refill_min = 32;
@@ -616,8 +620,8 @@ static int render_tiles_wavefront(mi_ctx* c, const K1Args& k, const mi_camera_de
     };
 #define WF_TIMED(kind, call) do { if (stamp(kind) != MI_OK) return fail(MI_ERR_HIP, "event"); HIP_TRY(call); if (stamp(kind) != MI_OK) return fail(MI_ERR_HIP, "event"); } while (0)
 
-    for (uint32_t s0 = 0; s0 < spp; s0 += s_batch) {
-        a.s_base = s0; a.s_count = (s0 + s_batch <= spp) ? s_batch : (spp - s0);
+    for (uint32_t s0 = range.begin; s0 < range.end; s0 += s_batch) {
+        a.s_base = s0; a.s_count = (s0 + s_batch <= range.end) ? s_batch : (range.end - s0);
         int cur = 0;
         a.iter0 = 1;
         a.n_in = a.npix * a.s_count;
@@ -670,12 +674,22 @@ static int render_tiles_wavefront(mi_ctx* c, const K1Args& k, const mi_camera_de
 }
 
 static int render_tiles(mi_ctx* c, const mi_camera_desc* cam, const mi_render_opts* o, float* d_compact,
-                        uint32_t* d_sig, hipStream_t stream, mi_stats* st) {
+                        uint32_t* d_sig, hipStream_t stream, mi_stats* st, const SampleRange* partial = nullptr) {
     int rc = check_camera(cam);
     if (rc != MI_OK) return rc;
     if (!c->have_scene) return fail(MI_ERR_NO_SCENE, "no scene uploaded");
     if (!o || o->world < 1 || o->rank < 0 || o->rank >= o->world) return fail(MI_ERR_INVALID, "bad rank/world");
-    if (!d_compact) return fail(MI_ERR_INVALID, "output buffer is NULL");
+    SampleRange range = { 0u, cam->aa_sample_count, nullptr };
+    if (partial) {
+        range = *partial;
+        if (range.begin >= range.end || range.end > cam->aa_sample_count)
+            return fail(MI_ERR_INVALID, "sample range [%u, %u) is not inside [0, %u)", range.begin, range.end, cam->aa_sample_count);
+        if (!range.accum) return fail(MI_ERR_INVALID, "accumulator buffer is NULL");
+        if (cam->shading_mode != MI_SHADE_PATHTRACE || (o->variant != MI_VARIANT_DEFAULT && o->variant != MI_VARIANT_WAVEFRONT))
+            return fail(MI_ERR_UNSUPPORTED, "progressive rendering runs on the default (wavefront) path-tracing variant only");
+    }
+    const bool writes_image = range.end == cam->aa_sample_count;
+    if (!d_compact && writes_image) return fail(MI_ERR_INVALID, "output buffer is NULL");
     K1Args a;
     a.S = c->S;
     make_camera(cam, &a.C);
@@ -719,7 +733,7 @@ static int render_tiles(mi_ctx* c, const mi_camera_desc* cam, const mi_render_op
     if (phong)
         HIP_TRY(launch_phong(a, n_blocks, a.sig != nullptr, stream));
     else if (variant == MI_VARIANT_WAVEFRONT) {
-        int rcw = render_tiles_wavefront(c, a, cam, wa, wf_batch, lds, d_compact, a.sig, stream);
+        int rcw = render_tiles_wavefront(c, a, cam, wa, wf_batch, lds, d_compact, a.sig, range, stream);
         if (rcw != MI_OK) return rcw;
     } else if (pooled)
         HIP_TRY(launch_megakernel_pooled(a, padded, lds, a.sig != nullptr, diag, c->lds_bytes, stream));
@@ -739,7 +753,7 @@ static int render_tiles(mi_ctx* c, const mi_camera_desc* cam, const mi_render_op
             pixels += (uint64_t)w * h;
         }
         st->pixels = pixels;
-        st->samples = pixels * cam->aa_sample_count;
+        st->samples = pixels * (range.end - range.begin);
         st->tiles = a.R.my_tiles; st->tiles_padded = padded;
         st->scene_bytes = (uint32_t)c->blob_bytes; st->scene_in_lds = lds ? 1u : 0u;
     }
@@ -751,6 +765,15 @@ extern "C" int mi_render_tiles_device(mi_ctx* c, const mi_camera_desc* cam, cons
     if (!c) return fail(MI_ERR_INVALID, "ctx is NULL");
     HIP_TRY(hipSetDevice(c->device));
     return render_tiles(c, cam, opts, (float*)d_compact_f32, (uint32_t*)d_sig_u32, (hipStream_t)stream, stats);
+}
+
+extern "C" int mi_render_samples_device(mi_ctx* c, const mi_camera_desc* cam, const mi_render_opts* opts,
+                                        uint32_t sample_begin, uint32_t sample_end, void* d_accum_f32x4,
+                                        void* d_compact_f32, void* d_sig_u32, void* stream, mi_stats* stats) {
+    if (!c) return fail(MI_ERR_INVALID, "ctx is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    SampleRange r = { sample_begin, sample_end, (float4*)d_accum_f32x4 };
+    return render_tiles(c, cam, opts, (float*)d_compact_f32, (uint32_t*)d_sig_u32, (hipStream_t)stream, stats, &r);
 }
 
 extern "C" int mi_unpermute_device(mi_ctx* c, const mi_camera_desc* cam, int32_t world, const void* d_gathered_f32,

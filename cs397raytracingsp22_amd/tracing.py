@@ -112,6 +112,20 @@ class Context:
                                                    stream, C.byref(st)))
         return st
 
+    def render_samples_device(self, cam: Camera, sample_begin: int, sample_end: int, d_accum: int,
+                              d_compact: Optional[int] = None, d_sig: Optional[int] = None, seed: int = 1,
+                              rank: int = 0, world: int = 1, stream: Optional[int] = None):
+        """mi_render_samples_device: add samples [sample_begin, sample_end) of every pixel, in order, to the
+        caller-held accumulator (float4 per compact pixel).  The call that reaches aa_sample_count also
+        writes the means to d_compact.  Progressive display and checkpoint / resume are built on this."""
+        pod = cam.to_pod()
+        opts = abi.mi_render_opts(seed=seed, rank=rank, world=world, variant=abi.MI_VARIANT_DEFAULT,
+                                  want_signature=int(d_sig is not None))
+        st = abi.mi_stats()
+        abi.check(self._lib.mi_render_samples_device(self._h, C.byref(pod), C.byref(opts), sample_begin, sample_end,
+                                                     d_accum, d_compact, d_sig, stream, C.byref(st)))
+        return st
+
     def unpermute_device(self, cam: Camera, world: int, d_gathered: int, d_image: int, stream: Optional[int] = None):
         pod = cam.to_pod()
         abi.check(self._lib.mi_unpermute_device(self._h, C.byref(pod), world, d_gathered, d_image, stream))

@@ -232,6 +232,20 @@ int  mi_render(mi_ctx* ctx, const mi_camera_desc* cam, const mi_render_opts* opt
 int  mi_compact_size(const mi_camera_desc* cam, int32_t world, uint32_t* tiles_total, uint32_t* tiles_padded);
 int  mi_render_tiles_device(mi_ctx* ctx, const mi_camera_desc* cam, const mi_render_opts* opts,
                             void* d_compact_f32, void* d_sig_u32, void* stream, mi_stats* stats);
+/* Progressive / resumable accumulation (the reference renders all `aa_sample_count` samples of a
+ * pixel in one go, tracing.rs:233-241; this splits that loop without changing its result).
+ * Traces samples [sample_begin, sample_end) of every pixel of this rank and adds them IN ORDER to the
+ * caller-held accumulator d_accum_f32x4[tiles_padded*MI_TILE*MI_TILE] (float4: xyz = running sums,
+ * w = bits of the running signature sum).  sample_begin == 0 starts the sums from zero (the buffer
+ * need not be cleared).  When sample_end == aa_sample_count the per-pixel means (and signatures) are
+ * written to d_compact_f32 / d_sig_u32 exactly as mi_render_tiles_device does; otherwise both may be
+ * NULL.  Calls must cover [0, aa_sample_count) in increasing, gap-free order; the accumulator may be
+ * copied out and back in between (checkpoint / resume, also into another context with the same
+ * scene, camera, seed, rank and world).  The final image is bit-identical to a one-call render.
+ * Default (wavefront) path-tracing variant only. */
+int  mi_render_samples_device(mi_ctx* ctx, const mi_camera_desc* cam, const mi_render_opts* opts,
+                              uint32_t sample_begin, uint32_t sample_end, void* d_accum_f32x4,
+                              void* d_compact_f32, void* d_sig_u32, void* stream, mi_stats* stats);
 int  mi_unpermute_device(mi_ctx* ctx, const mi_camera_desc* cam, int32_t world,
                          const void* d_gathered_f32, void* d_image_f32, void* stream);
 int  mi_tonemap_device(mi_ctx* ctx, const mi_camera_desc* cam,
