@@ -15,6 +15,7 @@
 // camera basis) are computed here with the same f32 operations, in the same order,
 // the reference performs per ray, so hoisting them does not change a single bit.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -108,6 +109,10 @@ struct mi_ctx {
     void* d_wf_samp = nullptr; size_t wf_samp_bytes = 0;
     void* d_wf_acc = nullptr; size_t wf_acc_bytes = 0;
     uint32_t* d_wf_cnt = nullptr;
+    // per-tile primary-ray masks over the kind-grouped list (see tile_masks)
+    std::vector<DObject> h_list; int h_n_tri = 0, h_n_sphere = 0;
+    std::vector<unsigned long long> h_tile_mask; void* d_tile_mask = nullptr; size_t tile_mask_bytes = 0;
+    mi_camera_desc mask_cam{}; bool mask_valid = false;
     uint64_t wf_max_paths = 0;                       // paths per batch; 0 = size from free HBM (MI_RT_WF_PATHS overrides)
     std::vector<hipEvent_t> wf_ev;                   // event pool for per-kernel timing of the pipeline
     float wf_ms[4] = { 0, 0, 0, 0 };                 // last frame: wf_main, wf_trav, wf_reduce totals (ms), launches
@@ -179,6 +184,7 @@ extern "C" void mi_ctx_destroy(mi_ctx* c) {
     if (c->d_wf_q) (void)hipFree(c->d_wf_q);
     if (c->d_wf_samp) (void)hipFree(c->d_wf_samp);
     if (c->d_wf_acc) (void)hipFree(c->d_wf_acc);
+    if (c->d_tile_mask) (void)hipFree(c->d_tile_mask);
     if (c->d_wf_cnt) (void)hipFree(c->d_wf_cnt);
     for (hipEvent_t e : c->wf_ev) (void)hipEventDestroy(e);
     if (c->ev_start) (void)hipEventDestroy(c->ev_start);
@@ -433,6 +439,7 @@ extern "C" int mi_scene_upload(mi_ctx* c, const mi_scene_desc* d) {
     uint8_t* b = (uint8_t*)c->blob;
     c->S.objects = (const DObject*)(b + off_obj);
     c->S.list = (const DObject*)(b + off_list);
+    c->h_list = list; c->h_n_tri = n_list[0]; c->h_n_sphere = n_list[1]; c->mask_valid = false;
     c->S.n_list_tri = n_list[0]; c->S.n_list_sphere = n_list[1]; c->S.n_list_plane = n_list[2]; c->S.n_list_volume = n_list[3];
     c->S.materials = (const DMaterial*)(b + off_mat);
     c->S.meshes = (const DMesh*)(b + off_mesh);
@@ -563,6 +570,91 @@ static int wf_prepare(mi_ctx* c, const mi_camera_desc* cam, uint32_t padded, WfA
     return wf_alloc(c, a, spp, s_batch);
 }
 
+// Primary-ray culling for the wavefront pipeline.  For every 32x32 tile: which Triangle / Sphere entries of
+// the kind-grouped list can a camera ray of that tile reach?  A perspective camera with lens_radius 0
+// sends every ray of a tile from the eye through the tile's pixel footprints — pixel centre +- 1 px
+// (tracing.rs:171-181: both jitter terms span +-0.5 px) — so the rays lie inside the pyramid spanned by
+// the four corner directions of the footprint, here widened by one more pixel (>= 5e-4 rad at any
+// resolution up to 2k rows, against f32 rounding of ~1e-7 in the generated directions).  An object that is
+// entirely on the outer side of one of the pyramid's four planes through the eye cannot be hit; it is
+// dropped from the tile's mask and its test — which would have missed — is not run.  f64 on the host,
+// a further 1e-4 scene-unit slack; any non-finite value or a singular camera basis keeps everything.
+// Planes and ConvexVolumes are never masked.  Returns false when masking does not apply.
+static bool tile_masks(mi_ctx* c, const mi_camera_desc* cam) {
+    const int n_ts = c->h_n_tri + c->h_n_sphere;
+    if (n_ts == 0 || n_ts > 64) return false;
+    // rays must leave the eye itself (no lens) towards the image plane (focus_dist > 0 keeps the direction's sign)
+    if (cam->projection_mode != MI_PROJ_PERSPECTIVE || cam->lens_radius != 0.0f || !(cam->focus_dist > 0.0f) || getenv("MI_RT_NO_TILE_MASK")) return false;
+    if (c->mask_valid && memcmp(&c->mask_cam, cam, sizeof *cam) == 0) return true;
+    const double W = cam->screen_width, H = cam->screen_height, p = 1.0 / H;
+    const double view[3] = { cam->view_dir[0], cam->view_dir[1], cam->view_dir[2] };
+    const double up[3] = { cam->up[0], cam->up[1], cam->up[2] };
+    double c0[3] = { view[1] * up[2] - view[2] * up[1], view[2] * up[0] - view[0] * up[2], view[0] * up[1] - view[1] * up[0] };
+    const double l0 = sqrt(c0[0] * c0[0] + c0[1] * c0[1] + c0[2] * c0[2]);
+    if (!(l0 > 1e-12) || !std::isfinite(l0)) return false;
+    for (double& v : c0) v /= l0;
+    // det of R = [c0 up -view]: a (near-)singular basis flattens the pyramid
+    const double det = c0[0] * (up[1] * -view[2] - up[2] * -view[1]) - up[0] * (c0[1] * -view[2] - c0[2] * -view[1])
+                     + -view[0] * (c0[1] * up[2] - c0[2] * up[1]);
+    if (!(fabs(det) > 1e-6) || !std::isfinite(det)) return false;
+    auto dir = [&](double px, double py, double* o) {           // R * (camera-space point on the image plane)
+        const double x = p * (px - 0.5 * W + 0.5), y = p * (0.5 + 0.5 * H - py), z = -(double)cam->focal_length;
+        for (int k = 0; k < 3; k++) o[k] = c0[k] * x + up[k] * y + -view[k] * z;
+    };
+    const uint32_t tx = (cam->screen_width + MI_TILE - 1) / MI_TILE, ty = (cam->screen_height + MI_TILE - 1) / MI_TILE;
+    c->h_tile_mask.assign((size_t)tx * ty, ~0ull);
+    const double margin_px = 2.0, slack = 1e-4;
+    const double eye[3] = { cam->eyepoint[0], cam->eyepoint[1], cam->eyepoint[2] };
+    for (uint32_t j = 0; j < ty; j++) for (uint32_t i = 0; i < tx; i++) {
+        const double x0 = (double)i * MI_TILE - margin_px, x1 = std::min<double>(W, (i + 1.0) * MI_TILE) - 1.0 + margin_px;
+        const double y0 = (double)j * MI_TILE - margin_px, y1 = std::min<double>(H, (j + 1.0) * MI_TILE) - 1.0 + margin_px;
+        double cs[4][3], ctr[3], n[4][3];
+        dir(x0, y0, cs[0]); dir(x1, y0, cs[1]); dir(x1, y1, cs[2]); dir(x0, y1, cs[3]);
+        dir(0.5 * (x0 + x1), 0.5 * (y0 + y1), ctr);
+        bool ok = true;
+        for (int k = 0; k < 4 && ok; k++) {
+            const double* a = cs[k]; const double* b = cs[(k + 1) & 3];
+            double v[3] = { a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0] };
+            const double l = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+            if (!(l > 0.0) || !std::isfinite(l)) { ok = false; break; }
+            const double sgn = (v[0] * ctr[0] + v[1] * ctr[1] + v[2] * ctr[2]) < 0.0 ? -1.0 : 1.0;      // inward
+            for (int q = 0; q < 3; q++) n[k][q] = sgn * v[q] / l;
+        }
+        if (!ok) continue;
+        unsigned long long mask = ~0ull;
+        for (int e = 0; e < n_ts; e++) {
+            const DObject& ob = c->h_list[(size_t)e];
+            bool cull = false;
+            for (int k = 0; k < 4 && !cull; k++) {
+                if (e < c->h_n_tri) {                       // a, a + e1, a + e2 all outside plane k
+                    bool all_out = true;
+                    for (int vtx = 0; vtx < 3 && all_out; vtx++) {
+                        double d = 0.0;
+                        for (int q = 0; q < 3; q++) {
+                            double pq = (double)ob.f[q] + (vtx == 1 ? (double)ob.f[3 + q] : vtx == 2 ? (double)ob.f[6 + q] : 0.0);
+                            d += (pq - eye[q]) * n[k][q];
+                        }
+                        all_out = d < -slack;              // false for NaN
+                    }
+                    cull = all_out;
+                } else {
+                    double d = 0.0;
+                    for (int q = 0; q < 3; q++) d += ((double)ob.f[q] - eye[q]) * n[k][q];
+                    cull = d < -(fabs((double)ob.f[3]) + slack);
+                }
+            }
+            if (cull) mask &= ~(1ull << e);
+        }
+        c->h_tile_mask[(size_t)j * tx + i] = mask;
+    }
+    c->mask_cam = *cam; c->mask_valid = false;              // valid once uploaded
+    if (getenv("MI_RT_DEBUG_MASK")) {
+        size_t bits = 0; for (auto m : c->h_tile_mask) bits += (size_t)__builtin_popcountll(m & ((n_ts >= 64) ? ~0ull : ((1ull << n_ts) - 1ull)));
+        fprintf(stderr, "[mi_rt] tile masks: %zu tiles, %.2f of %d list entries kept per tile\n", c->h_tile_mask.size(), (double)bits / (double)c->h_tile_mask.size(), n_ts);
+    }
+    return true;
+}
+
 // Samples [begin, end) of every pixel, added in order to `accum` (nullptr = the context's own buffer).
 // begin == 0 starts the sums from zero; end == aa_sample_count also writes the per-pixel means.
 struct SampleRange { uint32_t begin, end; float4* accum; };
@@ -585,7 +677,18 @@ static int render_tiles_wavefront(mi_ctx* c, const K1Args& k, const mi_camera_de
     a.trav_pfx = d_trav_pfx;
     a.trav_q = (uint32_t*)c->d_wf_q; a.samp = (float4*)c->d_wf_samp; a.accum = range.accum ? range.accum : (float4*)c->d_wf_acc;
     a.out = d_compact; a.sig = d_sig;
-    a.diag = nullptr;
+    a.tile_mask = nullptr;
+    if (tile_masks(c, cam)) {
+        if (!c->mask_valid) {
+            int rcm = ensure(&c->d_tile_mask, &c->tile_mask_bytes, c->h_tile_mask.size() * sizeof(unsigned long long));
+            if (rcm != MI_OK) return rcm;
+            HIP_TRY(hipMemcpyAsync(c->d_tile_mask, c->h_tile_mask.data(), c->h_tile_mask.size() * sizeof(unsigned long long), hipMemcpyHostToDevice, stream));
+            c->mask_valid = true;
+        }
+        a.tile_mask = (const unsigned long long*)c->d_tile_mask;
+    }
+    a.diag = nullptr;           // developer builds (-DPT_WF_STAMPS): phase stamps of wf_main
+    if (getenv("MI_RT_WF_STAMPS")) { a.diag = c->d_diag; HIP_TRY(hipMemsetAsync(c->d_diag, 0, 16 * sizeof(unsigned long long), stream)); }
     a.refill_min = 32;
     if (const char* e = getenv("MI_RT_WF_REFILL")) a.refill_min = (uint32_t)atoi(e);
     if (a.refill_min < 1) a.refill_min = 1;

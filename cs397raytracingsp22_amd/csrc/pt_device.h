@@ -215,6 +215,9 @@ struct WfArgs {
     float4* accum;        // [npix] running per-pixel sum (xyz) and signature sum (w bits)
     float*    out;        // compact framebuffer [tiles_padded][1024][3]
     uint32_t* sig;        // or nullptr
+    // Primary rays only: bit k of tile_mask[global tile] = entry k of the kind-grouped list can be hit by a
+    // camera ray of that 32x32 tile (conservative host-side frustum test; nullptr = test everything).
+    const PT_CONST_AS unsigned long long* tile_mask;
     unsigned long long* diag;   // developer builds with -DPT_WF_STAMPS: [16] summed s_memtime deltas of sampled wf_main waves
 };
 

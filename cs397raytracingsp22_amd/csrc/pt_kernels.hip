@@ -594,6 +594,36 @@ __device__ __forceinline__ void intersect_list(const DScene& S, f3 o, f3 d, floa
     }
 }
 
+// Same walk for CAMERA rays of one tile: entries whose bit in `mask` is clear cannot be reached by any
+// ray of that tile (host-side conservative frustum test, mi_rt.cpp tile_masks), so skipping them
+// skips tests that would have missed.  `mask` is wave-uniform (SGPRs); planes and volumes are never
+// masked (a volume draws its random number for the whole ray LINE, geometry.rs:505).
+__device__ __forceinline__ void intersect_list_masked(const DScene& S, unsigned long long mask, f3 o, f3 d,
+                                                      float t_min, float t_max, Rng& rng, Best& best) {
+    auto L = S.list;
+    const int n_tri = S.n_list_tri, n_ts = S.n_list_tri + S.n_list_sphere;
+    unsigned long long m = mask & ((n_ts >= 64) ? ~0ull : ((1ull << n_ts) - 1ull));
+    while (m != 0ull) {
+        const int k = __ffsll((long long)m) - 1;
+        m &= m - 1ull;
+        auto r0 = &L[k];
+        if (k < n_tri) {
+            float t0, u0, v0;
+            bool ok0 = tri_t(o, d, ld3(r0->f), ld3(r0->f + 3), ld3(r0->f + 6), t_min, t_max, t0, u0, v0);
+            consider_list(best, ok0, t0, r0->index, -1);
+        } else {
+            float t;
+            bool ok = sphere_t(o, d, ld3(r0->f), r0->f[4], t_min, t_max, t);
+            consider_list(best, ok, t, r0->index, -2);
+        }
+    }
+    const int end = n_ts + S.n_list_plane + S.n_list_volume;
+    for (int k = n_ts; k < end; k++) {
+        auto ob = &L[k];
+        test_object(ob, ob->index, o, d, t_min, t_max, rng, best);
+    }
+}
+
 // Material::scatter (materials.rs) for the resolved surface; returns the new direction
 // and the throughput factor dot_term*brdf/pdf of tracing.rs:313-316.
 // Material::scatter proper: new direction, attenuation (`.1` of the reference's tuple), 1/pdf.
@@ -1554,7 +1584,15 @@ __global__ __launch_bounds__(kBlock, PT_MAIN_WAVES) void wf_main(WfArgs A) {
     bool enters = false;
     best.obj = -1; best.t = 0.0f; best.tri = -1; best.u = best.v = 0.0f;
     if (alive) {
-        intersect_list(S, P.o, P.d, t_min, t_max, P.rng, best);
+        if (A.iter0 && A.tile_mask) {
+            // all 256 paths of a block belong to one tile (1024 | npix, 256 | 1024): wave-uniform mask
+            const uint32_t slot0 = ((blockIdx.x * kBlock) % A.npix) / kTilePixels;
+            const uint32_t tile0 = slot0 * (uint32_t)A.R.world + (uint32_t)A.R.rank;
+            const unsigned long long mask = A.tile_mask[tile0 < A.R.tiles_total ? tile0 : 0u];
+            intersect_list_masked(S, mask, P.o, P.d, t_min, t_max, P.rng, best);
+        } else {
+            intersect_list(S, P.o, P.d, t_min, t_max, P.rng, best);
+        }
         f3 oo, od, inv; int ti, tend, ttb;
         enters = enter_next_mesh(S, B, tm, P.o, P.d, t_min, t_max, oo, od, inv, ti, tend, ttb);
     }
