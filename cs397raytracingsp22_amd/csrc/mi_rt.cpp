@@ -110,7 +110,9 @@ struct mi_ctx {
     void* d_wf_acc = nullptr; size_t wf_acc_bytes = 0;
     uint32_t* d_wf_cnt = nullptr;
     // per-tile primary-ray masks over the kind-grouped list (see tile_masks)
-    std::vector<DObject> h_list; int h_n_tri = 0, h_n_sphere = 0;
+    std::vector<DObject> h_list; int h_n_tri = 0, h_n_sphere = 0, h_n_unmasked = 0;   // planes + volumes: never masked
+    struct MeshBox { bool cullable; double corner[8][3]; };
+    std::vector<MeshBox> h_mesh_box;                 // world-space corners of every live mesh's root box
     std::vector<unsigned long long> h_tile_mask; void* d_tile_mask = nullptr; size_t tile_mask_bytes = 0;
     mi_camera_desc mask_cam{}; bool mask_valid = false;
     uint64_t wf_max_paths = 0;                       // paths per batch; 0 = size from free HBM (MI_RT_WF_PATHS overrides)
@@ -406,6 +408,40 @@ extern "C" int mi_scene_upload(mi_ctx* c, const mi_scene_desc* d) {
             for (size_t i = 0; i < objs.size(); i++)
                 if (objs[i].kind == order[g]) { list.push_back(objs[i]); n_list[g]++; }
     }
+    // world-space corners of the root boxes (tile masks).  The rays reach object space through inv_transform
+    // (geometry.rs:304), so the corners come from ITS inverse (f64), not from `transform`; a projective
+    // inv_transform or a single-triangle mesh (no root box) is never culled.
+    c->h_mesh_box.assign(live.size(), mi_ctx::MeshBox{ false, {} });
+    for (size_t m = 0; m < live.size(); m++) {
+        const DMesh& M = live[m];
+        const float* it = M.inv_transform;
+        if (!(it[3] == 0.0f && it[7] == 0.0f && it[11] == 0.0f && it[15] == 1.0f)) continue;
+        const float* n0 = &nodes[(size_t)M.node_begin * 8];
+        int32_t tri_id; memcpy(&tri_id, &n0[7], 4);
+        if (tri_id >= 0) continue;
+        double a[4][8];                                   // [inv | I], Gauss-Jordan with partial pivoting
+        for (int r = 0; r < 4; r++) for (int q = 0; q < 4; q++) { a[r][q] = (double)it[q * 4 + r]; a[r][4 + q] = r == q ? 1.0 : 0.0; }
+        bool ok = true;
+        for (int col = 0; col < 4 && ok; col++) {
+            int piv = col;
+            for (int r = col + 1; r < 4; r++) if (fabs(a[r][col]) > fabs(a[piv][col])) piv = r;
+            if (!(fabs(a[piv][col]) > 1e-12)) { ok = false; break; }
+            if (piv != col) for (int q = 0; q < 8; q++) std::swap(a[piv][q], a[col][q]);
+            const double inv = 1.0 / a[col][col];
+            for (int q = 0; q < 8; q++) a[col][q] *= inv;
+            for (int r = 0; r < 4; r++) if (r != col) { const double f = a[r][col]; for (int q = 0; q < 8; q++) a[r][q] -= f * a[col][q]; }
+        }
+        if (!ok) continue;
+        mi_ctx::MeshBox& B = c->h_mesh_box[m];
+        B.cullable = true;
+        for (int k = 0; k < 8; k++) {
+            const double q[3] = { (double)((k & 1) ? n0[4] : n0[0]), (double)((k & 2) ? n0[5] : n0[1]), (double)((k & 4) ? n0[6] : n0[2]) };
+            for (int r = 0; r < 3; r++) {
+                B.corner[k][r] = a[r][4] * q[0] + a[r][5] * q[1] + a[r][6] * q[2] + a[r][7];
+                if (!std::isfinite(B.corner[k][r])) B.cullable = false;
+            }
+        }
+    }
     // one blob: objects | list | materials | meshes | nodes | tris | attrs | textures | texels
     auto align = [](size_t x) { return (x + 255) & ~(size_t)255; };
     size_t off_obj = 0;
@@ -439,7 +475,7 @@ extern "C" int mi_scene_upload(mi_ctx* c, const mi_scene_desc* d) {
     uint8_t* b = (uint8_t*)c->blob;
     c->S.objects = (const DObject*)(b + off_obj);
     c->S.list = (const DObject*)(b + off_list);
-    c->h_list = list; c->h_n_tri = n_list[0]; c->h_n_sphere = n_list[1]; c->mask_valid = false;
+    c->h_list = list; c->h_n_tri = n_list[0]; c->h_n_sphere = n_list[1]; c->h_n_unmasked = n_list[2] + n_list[3]; c->mask_valid = false;
     c->S.n_list_tri = n_list[0]; c->S.n_list_sphere = n_list[1]; c->S.n_list_plane = n_list[2]; c->S.n_list_volume = n_list[3];
     c->S.materials = (const DMaterial*)(b + off_mat);
     c->S.meshes = (const DMesh*)(b + off_mesh);
@@ -582,7 +618,8 @@ static int wf_prepare(mi_ctx* c, const mi_camera_desc* cam, uint32_t padded, WfA
 // Planes and ConvexVolumes are never masked.  Returns false when masking does not apply.
 static bool tile_masks(mi_ctx* c, const mi_camera_desc* cam) {
     const int n_ts = c->h_n_tri + c->h_n_sphere;
-    if (n_ts == 0 || n_ts > 64) return false;
+    const int n_mesh = (int)c->h_mesh_box.size();
+    if ((n_ts == 0 && n_mesh == 0) || n_ts > 64 || n_mesh > 32) return false;
     // rays must leave the eye itself (no lens) towards the image plane (focus_dist > 0 keeps the direction's sign)
     if (cam->projection_mode != MI_PROJ_PERSPECTIVE || cam->lens_radius != 0.0f || !(cam->focus_dist > 0.0f) || getenv("MI_RT_NO_TILE_MASK")) return false;
     if (c->mask_valid && memcmp(&c->mask_cam, cam, sizeof *cam) == 0) return true;
@@ -602,7 +639,11 @@ static bool tile_masks(mi_ctx* c, const mi_camera_desc* cam) {
         for (int k = 0; k < 3; k++) o[k] = c0[k] * x + up[k] * y + -view[k] * z;
     };
     const uint32_t tx = (cam->screen_width + MI_TILE - 1) / MI_TILE, ty = (cam->screen_height + MI_TILE - 1) / MI_TILE;
-    c->h_tile_mask.assign((size_t)tx * ty, ~0ull);
+    // [0, tiles): list masks; [tiles, 2*tiles): low 32 bits = mesh mask, bit 63 = DEAD tile (nothing reachable:
+    // every camera ray of the tile leaves the scene at once)
+    const size_t n_tiles = (size_t)tx * ty;
+    c->h_tile_mask.assign(2 * n_tiles, ~0ull);
+    for (size_t t = 0; t < n_tiles; t++) c->h_tile_mask[n_tiles + t] = 0xffffffffull;
     const double margin_px = 2.0, slack = 1e-4;
     const double eye[3] = { cam->eyepoint[0], cam->eyepoint[1], cam->eyepoint[2] };
     for (uint32_t j = 0; j < ty; j++) for (uint32_t i = 0; i < tx; i++) {
@@ -646,11 +687,37 @@ static bool tile_masks(mi_ctx* c, const mi_camera_desc* cam) {
             if (cull) mask &= ~(1ull << e);
         }
         c->h_tile_mask[(size_t)j * tx + i] = mask;
+        unsigned long long mm = 0xffffffffull;
+        for (int m = 0; m < n_mesh; m++) {
+            const mi_ctx::MeshBox& B = c->h_mesh_box[(size_t)m];
+            if (!B.cullable) continue;
+            bool cull = false;
+            for (int k = 0; k < 4 && !cull; k++) {
+                bool all_out = true;
+                for (int v = 0; v < 8 && all_out; v++) {
+                    double d = 0.0, len = 0.0;
+                    for (int q = 0; q < 3; q++) { const double w = B.corner[v][q] - eye[q]; d += w * n[k][q]; len += fabs(B.corner[v][q]) + fabs(eye[q]); }
+                    all_out = d < -(slack + 1e-5 * len);       // f32 rounding of the object-space ray and slabs
+                }
+                cull = all_out;
+            }
+            if (cull) mm &= ~(1ull << m);
+        }
+        const unsigned long long ts_bits = (n_ts >= 64) ? ~0ull : ((1ull << n_ts) - 1ull);
+        const unsigned long long mesh_bits = (n_mesh >= 32) ? 0xffffffffull : ((1ull << n_mesh) - 1ull);
+        if ((mask & ts_bits) == 0ull && (mm & mesh_bits) == 0ull && c->h_n_unmasked == 0) mm |= 1ull << 63;
+        c->h_tile_mask[n_tiles + (size_t)j * tx + i] = mm;
     }
     c->mask_cam = *cam; c->mask_valid = false;              // valid once uploaded
     if (getenv("MI_RT_DEBUG_MASK")) {
-        size_t bits = 0; for (auto m : c->h_tile_mask) bits += (size_t)__builtin_popcountll(m & ((n_ts >= 64) ? ~0ull : ((1ull << n_ts) - 1ull)));
-        fprintf(stderr, "[mi_rt] tile masks: %zu tiles, %.2f of %d list entries kept per tile\n", c->h_tile_mask.size(), (double)bits / (double)c->h_tile_mask.size(), n_ts);
+        size_t bits = 0, mbits = 0, dead = 0;
+        for (size_t t = 0; t < n_tiles; t++) {
+            bits += (size_t)__builtin_popcountll(c->h_tile_mask[t] & ((n_ts >= 64) ? ~0ull : ((1ull << n_ts) - 1ull)));
+            mbits += (size_t)__builtin_popcountll(c->h_tile_mask[n_tiles + t] & ((1ull << n_mesh) - 1ull));
+            dead += (size_t)(c->h_tile_mask[n_tiles + t] >> 63);
+        }
+        fprintf(stderr, "[mi_rt] tile masks: %zu tiles, %.2f of %d list entries and %.2f of %d meshes kept per tile, %zu dead tiles\n",
+                n_tiles, (double)bits / (double)n_tiles, n_ts, (double)mbits / (double)n_tiles, n_mesh, dead);
     }
     return true;
 }

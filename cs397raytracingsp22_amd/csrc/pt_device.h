@@ -217,6 +217,8 @@ struct WfArgs {
     uint32_t* sig;        // or nullptr
     // Primary rays only: bit k of tile_mask[global tile] = entry k of the kind-grouped list can be hit by a
     // camera ray of that 32x32 tile (conservative host-side frustum test; nullptr = test everything).
+    // tile_mask[tiles_total + tile]: low 32 bits = the same for the meshes' root boxes, bit 63 = nothing
+    // at all is reachable from this tile.
     const PT_CONST_AS unsigned long long* tile_mask;
     unsigned long long* diag;   // developer builds with -DPT_WF_STAMPS: [16] summed s_memtime deltas of sampled wf_main waves
 };

@@ -980,8 +980,10 @@ __global__ __launch_bounds__(kBlock) void pt_phong(K1Args A) {
 // returns false when no mesh is left.
 template <class BVH>
 __device__ __forceinline__ bool enter_next_mesh(const DScene& S, const BVH& B, int& m, f3 o, f3 d, float t_min, float t_max,
-                                                f3& oo, f3& od, f3& inv_d, int& ti, int& tend, int& ttb) {
+                                                f3& oo, f3& od, f3& inv_d, int& ti, int& tend, int& ttb,
+                                                uint32_t mesh_mask = 0xffffffffu) {
     for (; m < S.n_meshes; m++) {
+        if (m < 32 && !((mesh_mask >> m) & 1u)) continue;                // camera rays: root box out of the tile's reach
         auto M = &S.meshes[m];
         oo = xform_point(M->inv_transform, o);                           // geometry.rs:304
         od = xform_vector(M->inv_transform, d);
@@ -1502,10 +1504,24 @@ __global__ __launch_bounds__(kBlock, PT_MAIN_WAVES) void wf_main(WfArgs A) {
     Path P; Best best;
     uint32_t pix = 0, sample = 0;
     bool alive;
+    // camera rays: what can this block's tile reach at all?  (all 256 paths of a block belong to one tile:
+    // 1024 | npix, 256 | 1024, so both words are wave-uniform and stay in SGPRs)
+    unsigned long long list_mask = ~0ull, mesh_word = 0xffffffffull;
+    if (A.iter0 && A.tile_mask) {
+        const uint32_t slot0 = ((blockIdx.x * kBlock) % A.npix) / kTilePixels;
+        const uint32_t tile0 = slot0 * (uint32_t)A.R.world + (uint32_t)A.R.rank;
+        if (tile0 < A.R.tiles_total) { list_mask = A.tile_mask[tile0]; mesh_word = A.tile_mask[A.R.tiles_total + tile0]; }
+    }
     if (A.iter0) {
         // ---- Camera::generate_rays (tracing.rs:159-209) ----
         const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
         const bool valid = i < A.n_in;
+        if (!SIG && (mesh_word >> 63)) {
+            // nothing is reachable from this tile: every sample is the black background (tracing.rs:306).
+            // (With signatures on the rays are still generated: the signature folds in the RNG state.)
+            if (valid) A.samp[(size_t)(i / A.npix) * A.npix + (i % A.npix)] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            return;
+        }
         alive = valid;
         pix = valid ? (i % A.npix) : 0u;
         sample = A.s_base + (valid ? (i / A.npix) : 0u);
@@ -1584,17 +1600,10 @@ __global__ __launch_bounds__(kBlock, PT_MAIN_WAVES) void wf_main(WfArgs A) {
     bool enters = false;
     best.obj = -1; best.t = 0.0f; best.tri = -1; best.u = best.v = 0.0f;
     if (alive) {
-        if (A.iter0 && A.tile_mask) {
-            // all 256 paths of a block belong to one tile (1024 | npix, 256 | 1024): wave-uniform mask
-            const uint32_t slot0 = ((blockIdx.x * kBlock) % A.npix) / kTilePixels;
-            const uint32_t tile0 = slot0 * (uint32_t)A.R.world + (uint32_t)A.R.rank;
-            const unsigned long long mask = A.tile_mask[tile0 < A.R.tiles_total ? tile0 : 0u];
-            intersect_list_masked(S, mask, P.o, P.d, t_min, t_max, P.rng, best);
-        } else {
-            intersect_list(S, P.o, P.d, t_min, t_max, P.rng, best);
-        }
+        if (A.iter0 && A.tile_mask) intersect_list_masked(S, list_mask, P.o, P.d, t_min, t_max, P.rng, best);
+        else intersect_list(S, P.o, P.d, t_min, t_max, P.rng, best);
         f3 oo, od, inv; int ti, tend, ttb;
-        enters = enter_next_mesh(S, B, tm, P.o, P.d, t_min, t_max, oo, od, inv, ti, tend, ttb);
+        enters = enter_next_mesh(S, B, tm, P.o, P.d, t_min, t_max, oo, od, inv, ti, tend, ttb, (uint32_t)mesh_word);
     }
     // A ray that hits no object and enters no mesh ends its path at the next shade_ray level
     // (tracing.rs:306, background = 0).  Do that level now — same operations, same RNG state —
