@@ -174,12 +174,15 @@ def main():
                        "path_depth": cam.path_depth, "parallelism": f"tiles32x32_mod{world}",
                        "caller": "python ctypes over the C ABI (include/mi_rt.h)",
                        "segments_per_sample": segs, "msegments_per_s": value * segs},
-            "roofline": {"bound": "hbm", "kernel": "K1w pipeline (wf_main + wf_trav per segment, wf_reduce)" if per_step["launches"] else "pt_megakernel",
+            "roofline": {"bound": "hbm", "kernel": "K1w pipeline (wf_main + wf_trav per segment, wf_reduce)" if args.variant in (0, 7) else "pt_megakernel",
                          "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel_ms": kernel_ms, "algorithmic_bytes_per_sample": b_sample,
-                         "per_step_ms": {"wf_main": per_step["wf_main_ms"], "wf_trav": per_step["wf_trav_ms"],
-                                         "wf_reduce": per_step["wf_reduce_ms"], "launches": per_step["launches"]},
+                         # per-kernel HIP events cost ~0.4 ms of barriers per frame: the library records them on
+                         # single-rank renders only (MI_RT_WF_KERNEL_TIMING=1 forces them)
+                         "per_step_ms": ({"wf_main": per_step["wf_main_ms"], "wf_trav": per_step["wf_trav_ms"],
+                                          "wf_reduce": per_step["wf_reduce_ms"], "launches": per_step["launches"]}
+                                         if per_step["launches"] else None),
                          "note": "algorithmic bytes = what traversal dereferences (SURVEY.md §8d): object list and BVH are "
                                  "SGPR/LDS-resident; `traffic` = PMC-measured HBM bytes per pipeline pass, i.e. the path "
                                  "state streamed between the phase kernels plus the framebuffer"},

@@ -40,6 +40,8 @@ size_t pooled_park_bytes(uint32_t tiles_padded);
 hipError_t launch_wf_main(const WfArgs& a, uint32_t n_blocks, bool sig, hipStream_t stream);
 hipError_t launch_phong(const K1Args& a, uint32_t n_blocks, bool sig, hipStream_t stream);
 hipError_t launch_wf_trav(const WfArgs& a, uint32_t n_blocks, int lds_mode, size_t lds_bytes, hipStream_t stream);
+hipError_t launch_wf_prefix(uint32_t* out_count, uint32_t* trav_count, uint32_t* in_count, uint32_t* in_blkpfx,
+                            uint32_t* trav_pfx, uint32_t* hdr, hipStream_t stream);
 hipError_t launch_wf_reduce(const WfArgs& a, bool first_batch, bool last_batch, hipStream_t stream);
 hipError_t launch_unpermute(const float* gathered, float* image, uint32_t width, uint32_t height, uint32_t tiles_x,
                             uint32_t world, uint32_t tiles_padded, hipStream_t stream);
@@ -109,6 +111,9 @@ struct mi_ctx {
     void* d_wf_samp = nullptr; size_t wf_samp_bytes = 0;
     void* d_wf_acc = nullptr; size_t wf_acc_bytes = 0;
     uint32_t* d_wf_cnt = nullptr;
+    hipStream_t copy_stream = nullptr;               // header read-back, off the compute stream
+    hipEvent_t ev_hdr_ready = nullptr, ev_hdr_copied = nullptr;
+    uint32_t* h_hdr = nullptr;                       // pinned, 4 words
     // per-tile primary-ray masks over the kind-grouped list (see tile_masks)
     std::vector<DObject> h_list; int h_n_tri = 0, h_n_sphere = 0, h_n_unmasked = 0;   // planes + volumes: never masked
     struct MeshBox { bool cullable; double corner[8][3]; };
@@ -162,6 +167,10 @@ extern "C" int mi_ctx_create(int device, mi_ctx** out) {
     if (const char* e = getenv("MI_RT_WF_PATHS")) c->wf_max_paths = (uint64_t)atoll(e);
     c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     HIP_TRY(hipMalloc((void**)&c->d_wf_cnt, (9 * 256 + 64) * sizeof(uint32_t)));
+    HIP_TRY(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_hdr_ready, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_hdr_copied, hipEventDisableTiming));
+    HIP_TRY(hipHostMalloc((void**)&c->h_hdr, 4 * sizeof(uint32_t), hipHostMallocDefault));
     if (const char* e = getenv("MI_RT_LDS_PAD_KB")) c->lds_pad = (uint32_t)atoi(e) * 1024u;   // occupancy experiments
     if (c->vote_t < 1) c->vote_t = 1;
     if (c->k_steps < 1) c->k_steps = 1;
@@ -188,6 +197,10 @@ extern "C" void mi_ctx_destroy(mi_ctx* c) {
     if (c->d_wf_acc) (void)hipFree(c->d_wf_acc);
     if (c->d_tile_mask) (void)hipFree(c->d_tile_mask);
     if (c->d_wf_cnt) (void)hipFree(c->d_wf_cnt);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    if (c->ev_hdr_ready) (void)hipEventDestroy(c->ev_hdr_ready);
+    if (c->ev_hdr_copied) (void)hipEventDestroy(c->ev_hdr_copied);
+    if (c->h_hdr) (void)hipHostFree(c->h_hdr);
     for (hipEvent_t e : c->wf_ev) (void)hipEventDestroy(e);
     if (c->ev_start) (void)hipEventDestroy(c->ev_start);
     if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
@@ -553,9 +566,10 @@ static void make_camera(const mi_camera_desc* cam, DCamera* C) {
     C->ortho_dir[0] = od.x; C->ortho_dir[1] = od.y; C->ortho_dir[2] = od.z;
 }
 
-// K1w: the wavefront pipeline (pt_kernels.hip).  The host drives one iteration per path
-// segment and reads the per-shard counters back each iteration (live paths, traversal queue
-// lengths), so this variant synchronises `stream` internally.
+// K1w: the wavefront pipeline (pt_kernels.hip).  The host enqueues one iteration per path segment:
+// wf_main, wf_prefix (device-side bookkeeping of the shard counters), wf_trav.  It needs one number back
+// per iteration — the grid of the next wf_main — which arrives on a second stream while wf_trav runs, so
+// the compute stream never waits for the host; the call still returns only when the frame is done.
 //
 // Memory: path state is streamed through HBM — 2 x 96 B (ping/pong) + 4 B queue + 16 B sample
 // slot per path.  The batch is sized to the free HBM (288 GB on MI355X: the whole 1080p/256 spp
@@ -742,6 +756,8 @@ static int render_tiles_wavefront(mi_ctx* c, const K1Args& k, const mi_camera_de
     a.in_count = d_in_count; a.in_blkpfx = d_in_pfx;
     uint32_t* d_trav_pfx = d_in_pfx + 2 * S_ + 8;
     a.trav_pfx = d_trav_pfx;
+    uint32_t* d_hdr = d_trav_pfx + S_ + 8;
+    a.hdr = d_hdr;
     a.trav_q = (uint32_t*)c->d_wf_q; a.samp = (float4*)c->d_wf_samp; a.accum = range.accum ? range.accum : (float4*)c->d_wf_acc;
     a.out = d_compact; a.sig = d_sig;
     a.tile_mask = nullptr;
@@ -774,15 +790,16 @@ static int render_tiles_wavefront(mi_ctx* c, const K1Args& k, const mi_camera_de
     if (trav_lds_mode == 2) { trav_bpc = (uint32_t)((160u * 1024u) / (node_bytes ? node_bytes : 1)); if (trav_bpc > 8) trav_bpc = 8; if (trav_bpc < 2) trav_bpc = 2; }
     if (const char* e = getenv("MI_RT_WF_TRAV_BPC")) trav_bpc = (uint32_t)atoi(e);
     const uint32_t trav_blocks = (uint32_t)c->n_cus * trav_bpc;
-    uint32_t trav_rpl = 1;
-    if (const char* e = getenv("MI_RT_WF_TRAV_RPL")) trav_rpl = (uint32_t)atoi(e);
-    if (trav_rpl < 1) trav_rpl = 1;
-    std::vector<uint32_t> h(3 * S_), hin(4 * S_ + 1), htp(S_ + 1);
 
     // per-kernel timing: one event pair per launch, summed after the frame
     size_t ev_used = 0;
     std::vector<int> ev_kind;
+    // one event pair per launch is ~0.4 ms per frame of extra barriers: nothing on a whole frame (109 ms), 3 %
+    // of a 1/8 share, so multi-rank renders skip it unless asked (MI_RT_WF_KERNEL_TIMING=0/1 overrides)
+    bool per_kernel_timing = a.R.world == 1;
+    if (const char* e = getenv("MI_RT_WF_KERNEL_TIMING")) per_kernel_timing = atoi(e) != 0;
     auto stamp = [&](int kind) -> int {      // kind: 0 wf_main, 1 wf_trav, 2 wf_reduce; call before AND after the launch
+        if (!per_kernel_timing) return MI_OK;
         if (ev_used == c->wf_ev.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return MI_ERR_HIP; c->wf_ev.push_back(e); }
         if (hipEventRecord(c->wf_ev[ev_used++], stream) != hipSuccess) return MI_ERR_HIP;
         ev_kind.push_back(kind);
@@ -796,37 +813,25 @@ static int render_tiles_wavefront(mi_ctx* c, const K1Args& k, const mi_camera_de
         a.iter0 = 1;
         a.n_in = a.npix * a.s_count;
         uint32_t n_blocks = (a.n_in + kBlock - 1) / kBlock;
+        HIP_TRY(hipMemsetAsync(cnt, 0, (3 * S_ + 8) * sizeof(uint32_t), stream));   // wf_prefix re-zeroes them after every pass
         for (uint32_t it = 0; it <= cam->path_depth + 1u && n_blocks > 0; it++) {
-            HIP_TRY(hipMemsetAsync(cnt, 0, (3 * S_ + 8) * sizeof(uint32_t), stream));
             a.st_in = a.iter0 ? nullptr : bufs[cur];
             a.st_out = bufs[cur ^ 1];
             a.n_blocks_in = n_blocks;
             WF_TIMED(0, launch_wf_main(a, n_blocks, d_sig != nullptr, stream));
-            HIP_TRY(hipMemcpyAsync(h.data(), cnt, 3 * S_ * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-            HIP_TRY(hipStreamSynchronize(stream));
-            uint64_t n_trav = 0, n_live = 0;
-            uint32_t blk = 0, acc = 0;
-            for (size_t s2 = 0; s2 < 2 * S_; s2++) {       // class A shards, then class B shards
-                n_live += h[s2];
-                hin[s2] = h[s2];                       // in_count for the next iteration
-                hin[2 * S_ + s2] = blk;                // in_blkpfx
-                blk += (h[s2] + kBlock - 1) / kBlock;
-            }
-            hin[4 * S_] = blk;
-            for (size_t s2 = 0; s2 < S_; s2++) { htp[s2] = acc; acc += h[2 * S_ + s2]; }
-            htp[S_] = acc; n_trav = acc;
-            if (n_trav > 0) {
-                HIP_TRY(hipMemcpyAsync(d_trav_pfx, htp.data(), (S_ + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
-                a.n_trav = (uint32_t)n_trav;
-                // persistent walkers: enough blocks to fill the chip, but at least `rpl` rays per lane so
-                // that each wave reaches a steady state of refills (matters for small per-rank queues)
-                uint64_t blocks = (n_trav + (uint64_t)kBlock * trav_rpl - 1) / ((uint64_t)kBlock * trav_rpl);
-                if (blocks < 1) blocks = 1;
-                if (blocks > trav_blocks) blocks = trav_blocks;
-                WF_TIMED(1, launch_wf_trav(a, (uint32_t)blocks, trav_lds_mode, trav_lds_bytes, stream));
-            }
+            // device-side bookkeeping: tables for the next pass and for wf_trav, and the 3-word header the
+            // host needs (grid of the next pass, anything alive?) — copied back on its own stream while
+            // wf_trav runs, so the compute stream never waits for the host
+            HIP_TRY(launch_wf_prefix(cnt, cnt + 2 * S_, d_in_count, d_in_pfx, d_trav_pfx, d_hdr, stream));
+            HIP_TRY(hipEventRecord(c->ev_hdr_ready, stream));
+            HIP_TRY(hipStreamWaitEvent(c->copy_stream, c->ev_hdr_ready, 0));
+            HIP_TRY(hipMemcpyAsync(c->h_hdr, d_hdr, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->copy_stream));
+            HIP_TRY(hipEventRecord(c->ev_hdr_copied, c->copy_stream));
+            if (c->S.n_meshes > 0)       // persistent walkers; they leave at once when the queue is empty
+                WF_TIMED(1, launch_wf_trav(a, trav_blocks, trav_lds_mode, trav_lds_bytes, stream));
+            HIP_TRY(hipEventSynchronize(c->ev_hdr_copied));
+            const uint32_t blk = c->h_hdr[0], n_live = c->h_hdr[1];
             if (n_live == 0) break;
-            HIP_TRY(hipMemcpyAsync(d_in_count, hin.data(), (4 * S_ + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
             n_blocks = blk;
             cur ^= 1;
             a.iter0 = 0;
@@ -834,7 +839,7 @@ static int render_tiles_wavefront(mi_ctx* c, const K1Args& k, const mi_camera_de
         WF_TIMED(2, launch_wf_reduce(a, s0 == 0, s0 + a.s_count >= spp, stream));
     }
 #undef WF_TIMED
-    HIP_TRY(hipStreamSynchronize(stream));      // host temporaries (hin, htp) were read by async copies
+    HIP_TRY(hipStreamSynchronize(stream));
     c->wf_ms[0] = c->wf_ms[1] = c->wf_ms[2] = 0.0f; c->wf_ms[3] = (float)(ev_used / 2);
     for (size_t e = 0; e + 1 < ev_used; e += 2) {
         float ms = 0.0f;

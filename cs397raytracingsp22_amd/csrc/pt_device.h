@@ -209,7 +209,7 @@ struct WfArgs {
     uint32_t* trav_count; // [kWfShards] traversal queue length per shard
     uint32_t* trav_head;  // [0]: consumption head over the CONCATENATED per-shard queues (wf_trav grabs 256 entries per atomic)
     const PT_CONST_AS uint32_t* trav_pfx;   // [kWfShards + 1] exclusive prefix of trav_count (host-built)
-    uint32_t n_trav;      // total queue length of this iteration
+    const PT_CONST_AS uint32_t* hdr;   // [4] written by wf_prefix after every wf_main: blocks of the next pass, live paths, queue length
     uint32_t* trav_q;     // [cap] per-shard regions of positions (in st_out) whose ray entered a mesh root box
     float4* samp;         // [s_count][npix] finished samples: L.xyz, signature bits
     float4* accum;        // [npix] running per-pixel sum (xyz) and signature sum (w bits)

@@ -1669,6 +1669,16 @@ __device__ __forceinline__ void bvh_bind(BvhNodesLds& B, const DScene& S, int) {
 template <int LDS>
 __global__ __launch_bounds__(kBlock, PT_TRAV_WAVES) void wf_trav(WfArgs A) {
     const DScene& S = A.S;
+    // Work distribution over the CONCATENATED queue (virtual indices; shard s owns [trav_pfx[s], trav_pfx[s+1])):
+    // wave w owns chunk w outright, later chunks come from one shared cursor.  The static first chunk
+    // matters: 8192 waves all opening with an atomicAdd on ONE word cost ~240 us per launch (same-address
+    // atomics retire at ~88 / us), 2.6 ms per frame and most of the multi-rank overhead; a queue that
+    // the static chunks cover never touches the cursor at all.
+    const uint32_t n_q = A.hdr[2];
+    const uint32_t n_waves = gridDim.x * (kBlock / 64u);
+    const uint32_t chunk = 256u;          // 128 rays per grab: the cursor's round trip shows (trav x3); 1024: long tails (+5 %)
+    const bool shared_part = n_waves * chunk < n_q;                  // anything beyond the static chunks?
+    if (blockIdx.x * (kBlock / 64u) * chunk >= n_q) return;       // nothing for this block (then nothing is left over either)
     typename TravBvh<LDS>::type B;
     if (LDS != 0) {
         cf4_ptr gn = (cf4_ptr)S.nodes;
@@ -1684,11 +1694,11 @@ __global__ __launch_bounds__(kBlock, PT_TRAV_WAVES) void wf_trav(WfArgs A) {
     const int last_node = S.n_nodes - 1;
     const uint32_t lane = threadIdx.x & 63;
 
-    // wave-uniform work cursor: a chunk [wnext, wend) of the CONCATENATED queue (virtual indices;
-    // shard s owns [trav_pfx[s], trav_pfx[s+1])).  One atomicAdd per 256 rays.
-    const uint32_t n_q = A.n_trav;
-    uint32_t wnext = 0, wend = 0;
+    // wave-uniform work cursor: a chunk [wnext, wend) of the queue
+    const uint32_t wave_id = blockIdx.x * (kBlock / 64u) + (threadIdx.x >> 6);
+    uint32_t wnext = wave_id * chunk, wend = min(wnext + chunk, n_q);
     bool drained = false;
+    if (wnext >= n_q) { wnext = wend = 0; drained = true; }
     bool have = false;
     size_t pos = 0;
     f3 o = mk3(0.0f, 0.0f, 0.0f), d = o, too = o, tod = o, tinv = o;
@@ -1703,11 +1713,14 @@ __global__ __launch_bounds__(kBlock, PT_TRAV_WAVES) void wf_trav(WfArgs A) {
         const uint32_t n_idle = (uint32_t)__popcll(need);
         if ((n_idle >= A.refill_min || n_idle == 64u) && !drained) {
             if (wnext == wend) {
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(&A.trav_head[0], 256u);
-                base = (uint32_t)__shfl((int)base, 0);
+                // shared cursor, counted from the end of the static chunks
+                uint32_t base = n_q;
+                if (shared_part) {
+                    if (lane == 0) base = n_waves * chunk + atomicAdd(&A.trav_head[0], chunk);
+                    base = (uint32_t)__shfl((int)base, 0);
+                }
                 if (base >= n_q) drained = true;
-                else { wnext = base; wend = min(base + 256u, n_q); }
+                else { wnext = base; wend = min(base + chunk, n_q); }
             }
             const uint32_t avail = wend - wnext;
             const uint32_t rank = (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
@@ -1776,6 +1789,42 @@ __global__ __launch_bounds__(kBlock, PT_TRAV_WAVES) void wf_trav(WfArgs A) {
                 have = false;
             }
         }
+    }
+}
+
+// After every wf_main: turn the per-shard append counters into the tables the next kernels index with —
+// in_count / in_blkpfx (class A shards, then class B shards) for the next wf_main, trav_pfx for wf_trav —
+// and a 3-word header (blocks of the next pass, live paths, queue length).  One block; keeps the host out
+// of the critical path: it reads the header back on a second stream while wf_trav runs.
+__global__ __launch_bounds__(256) void wf_prefix(uint32_t* __restrict__ out_count, uint32_t* __restrict__ trav_count,
+                                                 uint32_t* __restrict__ in_count, uint32_t* __restrict__ in_blkpfx,
+                                                 uint32_t* __restrict__ trav_pfx, uint32_t* __restrict__ hdr) {
+    __shared__ uint32_t sc[4][256];
+    const uint32_t t = threadIdx.x;
+    const uint32_t a = out_count[t], b = out_count[kWfShards + t], q = trav_count[t];
+    out_count[t] = 0; out_count[kWfShards + t] = 0; trav_count[t] = 0;       // ready for the next wf_main
+    if (t == 0) trav_count[kWfShards] = 0;                                  // trav_head, the walkers' shared cursor
+    in_count[t] = a; in_count[kWfShards + t] = b;
+    const uint32_t va = (a + kBlock - 1) / kBlock, vb = (b + kBlock - 1) / kBlock;
+    uint32_t x0 = va, x1 = vb, x2 = q, x3 = a + b;
+    sc[0][t] = x0; sc[1][t] = x1; sc[2][t] = x2; sc[3][t] = x3;
+    __syncthreads();
+    for (uint32_t d = 1; d < 256; d <<= 1) {           // inclusive Hillis-Steele scans, four at once
+        uint32_t y0 = 0, y1 = 0, y2 = 0, y3 = 0;
+        if (t >= d) { y0 = sc[0][t - d]; y1 = sc[1][t - d]; y2 = sc[2][t - d]; y3 = sc[3][t - d]; }
+        __syncthreads();
+        x0 += y0; x1 += y1; x2 += y2; x3 += y3;
+        sc[0][t] = x0; sc[1][t] = x1; sc[2][t] = x2; sc[3][t] = x3;
+        __syncthreads();
+    }
+    const uint32_t blocks_a = sc[0][255];
+    in_blkpfx[t] = x0 - va;
+    in_blkpfx[kWfShards + t] = blocks_a + (x1 - vb);
+    trav_pfx[t] = x2 - q;
+    if (t == 255) {
+        in_blkpfx[2 * kWfShards] = blocks_a + x1;
+        trav_pfx[kWfShards] = x2;
+        hdr[0] = blocks_a + x1; hdr[1] = x3; hdr[2] = x2; hdr[3] = 0;
     }
 }
 
@@ -1909,6 +1958,11 @@ hipError_t launch_wf_trav(const WfArgs& a, uint32_t n_blocks, int lds_mode, size
     if (lds_mode == 1) hipLaunchKernelGGL((wf_trav<1>), grid, block, lds_bytes, stream, a);
     else if (lds_mode == 2) hipLaunchKernelGGL((wf_trav<2>), grid, block, lds_bytes, stream, a);
     else hipLaunchKernelGGL((wf_trav<0>), grid, block, 0, stream, a);
+    return hipGetLastError();
+}
+hipError_t launch_wf_prefix(uint32_t* out_count, uint32_t* trav_count, uint32_t* in_count, uint32_t* in_blkpfx,
+                            uint32_t* trav_pfx, uint32_t* hdr, hipStream_t stream) {
+    hipLaunchKernelGGL(wf_prefix, dim3(1), dim3(256), 0, stream, out_count, trav_count, in_count, in_blkpfx, trav_pfx, hdr);
     return hipGetLastError();
 }
 hipError_t launch_wf_reduce(const WfArgs& a, bool first_batch, bool last_batch, hipStream_t stream) {

@@ -24,4 +24,6 @@ for world in (1, 2, 4, 8):
         torch.cuda.synchronize()
         walls.append((time.perf_counter() - t0) * 1e3 / 3); kerns.append(k / 3)
     if world == 1: ref = walls[0]
+    pm = ctx.last_pipeline_ms()
+    print(f"RES world={world}: last rank pipeline {({k: round(v, 2) for k, v in pm.items()})}")
     print(f"RES world={world}: wall max {max(walls):.2f} mean {sum(walls)/len(walls):.2f} | kernel max {max(kerns):.2f} | host overhead {max(walls)-max(kerns):.2f} ms | speedup vs 1 rank {ref/max(walls):.2f}x", flush=True)
