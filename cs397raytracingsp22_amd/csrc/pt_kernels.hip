@@ -39,7 +39,8 @@
 #define PT_MAIN_WAVES 4     // wf_main: minimum waves per SIMD the register allocator must allow
 #endif
 #ifndef PT_TRAV_BURST
-#define PT_TRAV_BURST 6     // wf_trav: interior steps per vote (sweep: 2/4/6/8 -> 52.6/46.8/45.8/46.3 ms at refill 32)
+#define PT_TRAV_BURST 6     // wf_trav: interior steps per vote (sweep: 2/4/6/8 -> 52.6/46.8/45.8/46.3 ms at refill 32;
+                            // leaving a burst early when < 16/24/32 lanes are still on interior nodes: +1/+2/+5 ms)
 #endif
 #ifndef PT_TRAV_WAVES
 #define PT_TRAV_WAVES 6     // wf_trav: waves per SIMD (LDS admits 6 blocks of 26.8 KB per CU)
