@@ -660,6 +660,59 @@ static bool tile_masks(mi_ctx* c, const mi_camera_desc* cam) {
     for (size_t t = 0; t < n_tiles; t++) c->h_tile_mask[n_tiles + t] = 0xffffffffull;
     const double margin_px = 2.0, slack = 1e-4;
     const double eye[3] = { cam->eyepoint[0], cam->eyepoint[1], cam->eyepoint[2] };
+    // Test shapes.  The geometric argument needs the f32 intersection tests to be WELL CONDITIONED for every
+    // camera ray, or a test could "hit" a triangle it passes far from.  Moller-Trumbore (geometry.rs:434-446)
+    // computes u = (s.h)/a with a = -d.n: the rounding error of u is ~2^-22 |s||h| / |a|, and a test that passes
+    // t <= t_max has |a| >= |n| h_E / t_max (t's numerator s.n = h_E |n| does not depend on d; h_E = distance
+    // of the eye from the triangle's plane).  So with  G = 2^-22 S t_reach / (h_E alt_min)  (S = eye to
+    // farthest vertex, alt_min = smallest altitude, t_reach = max_trace_dist x the column norms of the camera
+    // basis) small enough (below) every accepted ray passes inside the triangle scaled by 1.01 about its
+    // centroid — which is the shape tested against the pyramid.  Triangles that fail the
+    // guard (eye almost in their plane, slivers, huge max_trace_dist) are simply never masked.
+    // Spheres (geometry.rs:395-408): the discriminant's rounding moves the silhouette by ~1e-6 relative;
+    // the radius is padded by 0.1 % plus 1e-5 of the centre distance.
+    struct Shape { bool cullable; double v[3][3]; double r; };
+    std::vector<Shape> shapes((size_t)n_ts);
+    {
+        double colmax = 0.0;
+        { const double lu = sqrt(up[0] * up[0] + up[1] * up[1] + up[2] * up[2]), lv = sqrt(view[0] * view[0] + view[1] * view[1] + view[2] * view[2]);
+          colmax = 1.0 + lu + lv; }                            // |R d| <= (|c0| + |up| + |view|) |d|, |c0| = 1
+        const double t_reach = (double)cam->max_trace_dist * colmax;
+        for (int e = 0; e < n_ts; e++) {
+            const DObject& ob = c->h_list[(size_t)e];
+            Shape& sh = shapes[(size_t)e];
+            sh.cullable = false; sh.r = 0.0;
+            if (e < c->h_n_tri) {
+                double P[3][3], cen[3] = { 0, 0, 0 };
+                for (int vtx = 0; vtx < 3; vtx++) for (int q = 0; q < 3; q++) {
+                    P[vtx][q] = (double)ob.f[q] + (vtx == 1 ? (double)ob.f[3 + q] : vtx == 2 ? (double)ob.f[6 + q] : 0.0);
+                    cen[q] += P[vtx][q] / 3.0;
+                }
+                const double e1[3] = { P[1][0] - P[0][0], P[1][1] - P[0][1], P[1][2] - P[0][2] };
+                const double e2[3] = { P[2][0] - P[0][0], P[2][1] - P[0][1], P[2][2] - P[0][2] };
+                const double e3[3] = { P[2][0] - P[1][0], P[2][1] - P[1][1], P[2][2] - P[1][2] };
+                const double nn[3] = { e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0] };
+                const double area2 = sqrt(nn[0] * nn[0] + nn[1] * nn[1] + nn[2] * nn[2]);
+                auto len = [](const double* w) { return sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]); };
+                const double emax = std::max(len(e1), std::max(len(e2), len(e3)));
+                double S = 0.0, hE = 0.0;
+                for (int vtx = 0; vtx < 3; vtx++) { const double w[3] = { P[vtx][0] - eye[0], P[vtx][1] - eye[1], P[vtx][2] - eye[2] }; S = std::max(S, len(w)); }
+                for (int q = 0; q < 3; q++) hE += (eye[q] - P[0][q]) * nn[q];
+                hE = fabs(hE) / area2;
+                const double alt_min = area2 / emax;
+                const double G = ldexp(1.0, -22) * S * t_reach / (hE * alt_min);
+                // (u, v) off by G moves the point by <= 2 G emax in the plane; scaling by 1.01 about the centroid moves
+                // every edge out by >= 0.0033 alt_min: G <= 1e-3 alt_min / emax keeps the ray inside the scaled triangle
+                sh.cullable = std::isfinite(G) && area2 > 0.0 && G <= 1e-3 * alt_min / emax;
+                for (int vtx = 0; vtx < 3; vtx++) for (int q = 0; q < 3; q++) sh.v[vtx][q] = cen[q] + (P[vtx][q] - cen[q]) * 1.01;
+            } else {
+                double dist = 0.0;
+                for (int q = 0; q < 3; q++) { sh.v[0][q] = (double)ob.f[q]; dist += (sh.v[0][q] - eye[q]) * (sh.v[0][q] - eye[q]); }
+                sh.r = fabs((double)ob.f[3]) * 1.001 + 1e-5 * sqrt(dist);
+                sh.cullable = std::isfinite(sh.r) && std::isfinite(dist);
+            }
+        }
+    }
     for (uint32_t j = 0; j < ty; j++) for (uint32_t i = 0; i < tx; i++) {
         const double x0 = (double)i * MI_TILE - margin_px, x1 = std::min<double>(W, (i + 1.0) * MI_TILE) - 1.0 + margin_px;
         const double y0 = (double)j * MI_TILE - margin_px, y1 = std::min<double>(H, (j + 1.0) * MI_TILE) - 1.0 + margin_px;
@@ -678,24 +731,22 @@ static bool tile_masks(mi_ctx* c, const mi_camera_desc* cam) {
         if (!ok) continue;
         unsigned long long mask = ~0ull;
         for (int e = 0; e < n_ts; e++) {
-            const DObject& ob = c->h_list[(size_t)e];
+            const Shape& sh = shapes[(size_t)e];
+            if (!sh.cullable) continue;
             bool cull = false;
             for (int k = 0; k < 4 && !cull; k++) {
-                if (e < c->h_n_tri) {                       // a, a + e1, a + e2 all outside plane k
+                if (e < c->h_n_tri) {                       // the three (scaled) vertices all outside plane k
                     bool all_out = true;
                     for (int vtx = 0; vtx < 3 && all_out; vtx++) {
                         double d = 0.0;
-                        for (int q = 0; q < 3; q++) {
-                            double pq = (double)ob.f[q] + (vtx == 1 ? (double)ob.f[3 + q] : vtx == 2 ? (double)ob.f[6 + q] : 0.0);
-                            d += (pq - eye[q]) * n[k][q];
-                        }
+                        for (int q = 0; q < 3; q++) d += (sh.v[vtx][q] - eye[q]) * n[k][q];
                         all_out = d < -slack;              // false for NaN
                     }
                     cull = all_out;
                 } else {
                     double d = 0.0;
-                    for (int q = 0; q < 3; q++) d += ((double)ob.f[q] - eye[q]) * n[k][q];
-                    cull = d < -(fabs((double)ob.f[3]) + slack);
+                    for (int q = 0; q < 3; q++) d += (sh.v[0][q] - eye[q]) * n[k][q];
+                    cull = d < -(sh.r + slack);
                 }
             }
             if (cull) mask &= ~(1ull << e);

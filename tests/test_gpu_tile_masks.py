@@ -102,3 +102,22 @@ def test_masked_mesh_roots_and_dead_tiles(gpu_ctx, orc, seed, extras):
     # without signatures the dead-tile shortcut is live (no ray is generated for a tile that sees nothing)
     g32, _, _, _ = gpu_ctx.render(sc.camera, seed=seed, want_u8=False, want_sig=False)
     assert np.array_equal(g32, f32)
+
+
+@pytest.mark.parametrize("height", [0.0, 1e-6, 1e-4, 1e-2])
+def test_eye_in_the_plane_of_a_large_triangle(gpu_ctx, orc, height):
+    """Grazing camera rays make Moller-Trumbore ill-conditioned (u, v of rays nearly in the triangle's plane are
+    rounding noise); such triangles must stay in every tile's mask (mi_rt.cpp tile_masks, guard G)."""
+    grey = Lambertian(albedo=(0.7, 0.7, 0.7), emission=(0.3, 0.3, 0.3))
+    objs = [Triangle(a=(-40.0, 0.0, -60.0), b=(40.0, 0.0, -60.0), c=(0.0, 0.0, 5.0), material=grey),
+            Triangle(a=(3.0, 0.0, -20.0), b=(9.0, 0.0, -20.0), c=(6.0, 0.0, -2.0), material=grey),       # off to the side
+            Sphere(center=(0.0, 1.0, -8.0), radius=1.0, material=Metal(albedo=(0.8, 0.8, 0.8), roughness=0.1))]
+    cam = Camera(eyepoint=(0.0, height, 2.0), view_dir=(0.0, 0.0, -1.0), up=(0.0, 1.0, 0.0), path_depth=3, path_samples=1,
+                 screen_width=256, screen_height=96, focal_length=0.6, focus_dist=5.0, lens_radius=0.0,
+                 aa_sample_count=16, max_trace_dist=100.0, gamma=2.0)
+    sc = Scene(cam, objs)
+    flat = sc.flatten()
+    gpu_ctx.upload(flat)
+    _, _, sig, _ = gpu_ctx.render(cam, seed=5, want_u8=False, want_sig=True)
+    _, _, rsig, _ = orc.OracleScene(flat).render(cam, seed=5, want_u8=False)
+    assert np.array_equal(sig, rsig)
