@@ -16,6 +16,8 @@
 // the reference performs per ray, so hoisting them does not change a single bit.
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <chrono>
+#include <thread>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -41,7 +43,7 @@ hipError_t launch_wf_main(const WfArgs& a, uint32_t n_blocks, bool sig, hipStrea
 hipError_t launch_phong(const K1Args& a, uint32_t n_blocks, bool sig, hipStream_t stream);
 hipError_t launch_wf_trav(const WfArgs& a, uint32_t n_blocks, int lds_mode, size_t lds_bytes, hipStream_t stream);
 hipError_t launch_wf_prefix(uint32_t* out_count, uint32_t* trav_count, uint32_t* in_count, uint32_t* in_blkpfx,
-                            uint32_t* trav_pfx, uint32_t* hdr, hipStream_t stream);
+                            uint32_t* trav_pfx, uint32_t* hdr, uint32_t* host_hdr, uint32_t seq, hipStream_t stream);
 hipError_t launch_wf_reduce(const WfArgs& a, bool first_batch, bool last_batch, hipStream_t stream);
 hipError_t launch_unpermute(const float* gathered, float* image, uint32_t width, uint32_t height, uint32_t tiles_x,
                             uint32_t world, uint32_t tiles_padded, hipStream_t stream);
@@ -111,9 +113,9 @@ struct mi_ctx {
     void* d_wf_samp = nullptr; size_t wf_samp_bytes = 0;
     void* d_wf_acc = nullptr; size_t wf_acc_bytes = 0;
     uint32_t* d_wf_cnt = nullptr;
-    hipStream_t copy_stream = nullptr;               // header read-back, off the compute stream
-    hipEvent_t ev_hdr_ready = nullptr, ev_hdr_copied = nullptr;
-    uint32_t* h_hdr = nullptr;                       // pinned, 4 words
+    uint32_t* h_hdr = nullptr;                       // pinned + device-mapped, 4 words: wf_prefix writes {blocks, live, queue, seq}
+    uint32_t* h_hdr_dev = nullptr;                   // its device-side address
+    uint32_t hdr_seq = 0;
     // per-tile primary-ray masks over the kind-grouped list (see tile_masks)
     std::vector<DObject> h_list; int h_n_tri = 0, h_n_sphere = 0, h_n_unmasked = 0;   // planes + volumes: never masked
     struct MeshBox { bool cullable; double corner[8][3]; };
@@ -167,10 +169,9 @@ extern "C" int mi_ctx_create(int device, mi_ctx** out) {
     if (const char* e = getenv("MI_RT_WF_PATHS")) c->wf_max_paths = (uint64_t)atoll(e);
     c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     HIP_TRY(hipMalloc((void**)&c->d_wf_cnt, (9 * 256 + 64) * sizeof(uint32_t)));
-    HIP_TRY(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
-    HIP_TRY(hipEventCreateWithFlags(&c->ev_hdr_ready, hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&c->ev_hdr_copied, hipEventDisableTiming));
-    HIP_TRY(hipHostMalloc((void**)&c->h_hdr, 4 * sizeof(uint32_t), hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void**)&c->h_hdr, 4 * sizeof(uint32_t), hipHostMallocMapped));
+    memset(c->h_hdr, 0, 4 * sizeof(uint32_t));
+    HIP_TRY(hipHostGetDevicePointer((void**)&c->h_hdr_dev, c->h_hdr, 0));
     if (const char* e = getenv("MI_RT_LDS_PAD_KB")) c->lds_pad = (uint32_t)atoi(e) * 1024u;   // occupancy experiments
     if (c->vote_t < 1) c->vote_t = 1;
     if (c->k_steps < 1) c->k_steps = 1;
@@ -197,9 +198,6 @@ extern "C" void mi_ctx_destroy(mi_ctx* c) {
     if (c->d_wf_acc) (void)hipFree(c->d_wf_acc);
     if (c->d_tile_mask) (void)hipFree(c->d_tile_mask);
     if (c->d_wf_cnt) (void)hipFree(c->d_wf_cnt);
-    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
-    if (c->ev_hdr_ready) (void)hipEventDestroy(c->ev_hdr_ready);
-    if (c->ev_hdr_copied) (void)hipEventDestroy(c->ev_hdr_copied);
     if (c->h_hdr) (void)hipHostFree(c->h_hdr);
     for (hipEvent_t e : c->wf_ev) (void)hipEventDestroy(e);
     if (c->ev_start) (void)hipEventDestroy(c->ev_start);
@@ -871,16 +869,25 @@ static int render_tiles_wavefront(mi_ctx* c, const K1Args& k, const mi_camera_de
             a.n_blocks_in = n_blocks;
             WF_TIMED(0, launch_wf_main(a, n_blocks, d_sig != nullptr, stream));
             // device-side bookkeeping: tables for the next pass and for wf_trav, and the 3-word header the
-            // host needs (grid of the next pass, anything alive?) — copied back on its own stream while
-            // wf_trav runs, so the compute stream never waits for the host
-            HIP_TRY(launch_wf_prefix(cnt, cnt + 2 * S_, d_in_count, d_in_pfx, d_trav_pfx, d_hdr, stream));
-            HIP_TRY(hipEventRecord(c->ev_hdr_ready, stream));
-            HIP_TRY(hipStreamWaitEvent(c->copy_stream, c->ev_hdr_ready, 0));
-            HIP_TRY(hipMemcpyAsync(c->h_hdr, d_hdr, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->copy_stream));
-            HIP_TRY(hipEventRecord(c->ev_hdr_copied, c->copy_stream));
+            // host needs (grid of the next pass, anything alive?), which wf_prefix also stores in pinned host
+            // memory: the compute stream never waits for the host
+            const uint32_t seq = ++c->hdr_seq;
+            HIP_TRY(launch_wf_prefix(cnt, cnt + 2 * S_, d_in_count, d_in_pfx, d_trav_pfx, d_hdr, c->h_hdr_dev, seq, stream));
             if (c->S.n_meshes > 0)       // persistent walkers; they leave at once when the queue is empty
                 WF_TIMED(1, launch_wf_trav(a, trav_blocks, trav_lds_mode, trav_lds_bytes, stream));
-            HIP_TRY(hipEventSynchronize(c->ev_hdr_copied));
+            // wait for wf_prefix's header (written into pinned host memory) while wf_trav runs
+            {
+                volatile uint32_t* hh = c->h_hdr;
+                for (uint32_t spin = 1; hh[3] != seq; spin++) {
+                    if ((spin & 63u) == 0) {
+                        hipError_t q = hipStreamQuery(stream);
+                        if (q == hipSuccess) { if (hh[3] == seq) break; return fail(MI_ERR_HIP, "wavefront pipeline: stream drained without a header"); }
+                        if (q != hipErrorNotReady) return fail(MI_ERR_HIP, "wavefront pipeline: %s", hipGetErrorString(q));
+                    }
+                    std::this_thread::sleep_for(std::chrono::microseconds(20));
+                }
+                __atomic_thread_fence(__ATOMIC_ACQUIRE);
+            }
             const uint32_t blk = c->h_hdr[0], n_live = c->h_hdr[1];
             if (n_live == 0) break;
             n_blocks = blk;

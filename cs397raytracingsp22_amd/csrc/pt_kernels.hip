@@ -1796,10 +1796,11 @@ __global__ __launch_bounds__(kBlock, PT_TRAV_WAVES) void wf_trav(WfArgs A) {
 // After every wf_main: turn the per-shard append counters into the tables the next kernels index with —
 // in_count / in_blkpfx (class A shards, then class B shards) for the next wf_main, trav_pfx for wf_trav —
 // and a 3-word header (blocks of the next pass, live paths, queue length).  One block; keeps the host out
-// of the critical path: it reads the header back on a second stream while wf_trav runs.
+// of the critical path: the header lands in pinned host memory while wf_trav runs.
 __global__ __launch_bounds__(256) void wf_prefix(uint32_t* __restrict__ out_count, uint32_t* __restrict__ trav_count,
                                                  uint32_t* __restrict__ in_count, uint32_t* __restrict__ in_blkpfx,
-                                                 uint32_t* __restrict__ trav_pfx, uint32_t* __restrict__ hdr) {
+                                                 uint32_t* __restrict__ trav_pfx, uint32_t* __restrict__ hdr,
+                                                 volatile uint32_t* host_hdr, uint32_t seq) {
     __shared__ uint32_t sc[4][256];
     const uint32_t t = threadIdx.x;
     const uint32_t a = out_count[t], b = out_count[kWfShards + t], q = trav_count[t];
@@ -1826,6 +1827,11 @@ __global__ __launch_bounds__(256) void wf_prefix(uint32_t* __restrict__ out_coun
         in_blkpfx[2 * kWfShards] = blocks_a + x1;
         trav_pfx[kWfShards] = x2;
         hdr[0] = blocks_a + x1; hdr[1] = x3; hdr[2] = x2; hdr[3] = 0;
+        // the host's copy goes straight into pinned host memory (no copy kernel that would queue behind the
+        // persistent walkers): data, system-scope fence, then the sequence number the host polls
+        host_hdr[0] = blocks_a + x1; host_hdr[1] = x3; host_hdr[2] = x2;
+        __threadfence_system();
+        host_hdr[3] = seq;
     }
 }
 
@@ -1962,8 +1968,9 @@ hipError_t launch_wf_trav(const WfArgs& a, uint32_t n_blocks, int lds_mode, size
     return hipGetLastError();
 }
 hipError_t launch_wf_prefix(uint32_t* out_count, uint32_t* trav_count, uint32_t* in_count, uint32_t* in_blkpfx,
-                            uint32_t* trav_pfx, uint32_t* hdr, hipStream_t stream) {
-    hipLaunchKernelGGL(wf_prefix, dim3(1), dim3(256), 0, stream, out_count, trav_count, in_count, in_blkpfx, trav_pfx, hdr);
+                            uint32_t* trav_pfx, uint32_t* hdr, uint32_t* host_hdr, uint32_t seq, hipStream_t stream) {
+    hipLaunchKernelGGL(wf_prefix, dim3(1), dim3(256), 0, stream, out_count, trav_count, in_count, in_blkpfx, trav_pfx, hdr,
+                       (volatile uint32_t*)host_hdr, seq);
     return hipGetLastError();
 }
 hipError_t launch_wf_reduce(const WfArgs& a, bool first_batch, bool last_batch, hipStream_t stream) {
