@@ -23,7 +23,7 @@ MI_OBJ_SPHERE, MI_OBJ_TRIANGLE, MI_OBJ_PLANE, MI_OBJ_VOLUME, MI_OBJ_MESH = range
 MI_PROJ_ORTHOGRAPHIC, MI_PROJ_PERSPECTIVE = 0, 1
 MI_SHADE_PHONG, MI_SHADE_PATHTRACE = 0, 1
 MI_VARIANT_DEFAULT, MI_VARIANT_SIMPLE, MI_VARIANT_PARKED, MI_VARIANT_VOTED, MI_VARIANT_VOTED_DIAG = 0, 1, 2, 3, 4
-MI_VARIANT_POOLED, MI_VARIANT_POOLED_DIAG, MI_VARIANT_WAVEFRONT = 5, 6, 7
+MI_VARIANT_POOLED, MI_VARIANT_POOLED_DIAG, MI_VARIANT_WAVEFRONT, MI_VARIANT_RECURSIVE = 5, 6, 7, 8
 
 f3 = C.c_float * 3
 f16 = C.c_float * 16

@@ -41,6 +41,7 @@ hipError_t launch_megakernel_pooled(const K1Args& args, uint32_t tiles_padded, b
 size_t pooled_park_bytes(uint32_t tiles_padded);
 hipError_t launch_wf_main(const WfArgs& a, uint32_t n_blocks, bool sig, hipStream_t stream);
 hipError_t launch_phong(const K1Args& a, uint32_t n_blocks, bool sig, hipStream_t stream);
+hipError_t launch_branch(const K1Args& a, uint32_t n_blocks, uint32_t path_samples, bool sig, hipStream_t stream);
 hipError_t launch_wf_trav(const WfArgs& a, uint32_t n_blocks, int lds_mode, size_t lds_bytes, hipStream_t stream);
 hipError_t launch_wf_prefix(uint32_t* out_count, uint32_t* trav_count, uint32_t* in_count, uint32_t* in_blkpfx,
                             uint32_t* trav_pfx, uint32_t* hdr, uint32_t* host_hdr, uint32_t seq, hipStream_t stream);
@@ -512,8 +513,7 @@ static int check_camera(const mi_camera_desc* cam) {
         return fail(MI_ERR_INVALID, "unknown projection_mode %d", cam->projection_mode);
     if (cam->shading_mode != MI_SHADE_PATHTRACE && cam->shading_mode != MI_SHADE_PHONG)
         return fail(MI_ERR_INVALID, "unknown shading_mode %d", cam->shading_mode);
-    if (cam->path_samples != 1)
-        return fail(MI_ERR_UNSUPPORTED, "path_samples must be 1 on the GPU path (every configuration; tracing.rs:370)");
+    if (cam->path_samples == 0) return fail(MI_ERR_INVALID, "path_samples must be >= 1 (tracing.rs:318 divides by it)");
     if (cam->screen_width == 0 || cam->screen_height == 0 || cam->screen_width > 32768 || cam->screen_height > 32768)
         return fail(MI_ERR_INVALID, "bad image size %ux%u", cam->screen_width, cam->screen_height);
     if (cam->aa_sample_count == 0) return fail(MI_ERR_INVALID, "aa_sample_count must be >= 1");
@@ -918,7 +918,7 @@ static int render_tiles(mi_ctx* c, const mi_camera_desc* cam, const mi_render_op
         if (range.begin >= range.end || range.end > cam->aa_sample_count)
             return fail(MI_ERR_INVALID, "sample range [%u, %u) is not inside [0, %u)", range.begin, range.end, cam->aa_sample_count);
         if (!range.accum) return fail(MI_ERR_INVALID, "accumulator buffer is NULL");
-        if (cam->shading_mode != MI_SHADE_PATHTRACE || (o->variant != MI_VARIANT_DEFAULT && o->variant != MI_VARIANT_WAVEFRONT))
+        if (cam->shading_mode != MI_SHADE_PATHTRACE || cam->path_samples != 1 || (o->variant != MI_VARIANT_DEFAULT && o->variant != MI_VARIANT_WAVEFRONT))
             return fail(MI_ERR_UNSUPPORTED, "progressive rendering runs on the default (wavefront) path-tracing variant only");
     }
     const bool writes_image = range.end == cam->aa_sample_count;
@@ -928,6 +928,9 @@ static int render_tiles(mi_ctx* c, const mi_camera_desc* cam, const mi_render_op
     make_camera(cam, &a.C);
     for (int k = 0; k < 3; k++) { a.C.light[k] = c->point_light_pos[k]; a.C.ambient[k] = c->ambient[k]; }
     const bool phong = cam->shading_mode == MI_SHADE_PHONG;      // debug shader: own kernel, `variant` is ignored
+    // path_samples != 1 (tracing.rs:310) branches at every hit: the literal, recursive estimator (pt_branch)
+    const bool recursive = !phong && (cam->path_samples != 1 || o->variant == MI_VARIANT_RECURSIVE);
+    if (recursive && cam->path_depth > 64) return fail(MI_ERR_UNSUPPORTED, "recursive estimator: path_depth must be <= 64");
     uint32_t tx, ty, total, padded;
     tile_counts(cam, o->world, &tx, &ty, &total, &padded);
     a.R.seed = o->seed; a.R.rank = o->rank; a.R.world = o->world;
@@ -940,7 +943,7 @@ static int render_tiles(mi_ctx* c, const mi_camera_desc* cam, const mi_render_op
     a.out = d_compact;
     a.sig = (o->want_signature && d_sig) ? d_sig : nullptr;
     int variant = o->variant == MI_VARIANT_DEFAULT ? MI_VARIANT_WAVEFRONT : o->variant;
-    if (variant < MI_VARIANT_SIMPLE || variant > MI_VARIANT_WAVEFRONT) return fail(MI_ERR_INVALID, "unknown variant %d", o->variant);
+    if (variant < MI_VARIANT_SIMPLE || variant > MI_VARIANT_RECURSIVE) return fail(MI_ERR_INVALID, "unknown variant %d", o->variant);
     const bool pooled = variant == MI_VARIANT_POOLED || variant == MI_VARIANT_POOLED_DIAG;
     const bool diag = variant == MI_VARIANT_VOTED_DIAG || variant == MI_VARIANT_POOLED_DIAG;
     a.park = nullptr;
@@ -958,13 +961,15 @@ static int render_tiles(mi_ctx* c, const mi_camera_desc* cam, const mi_render_op
         HIP_TRY(hipMemsetAsync(c->d_diag, 0, 16 * sizeof(unsigned long long), stream));
     }
     WfArgs wa; uint32_t wf_batch = 1;
-    if (variant == MI_VARIANT_WAVEFRONT && !phong) {
+    if (variant == MI_VARIANT_WAVEFRONT && !phong && !recursive) {
         int rcp = wf_prepare(c, cam, padded, wa, wf_batch);
         if (rcp != MI_OK) return rcp;
     }
     HIP_TRY(hipEventRecord(c->ev_start, stream));
     if (phong)
         HIP_TRY(launch_phong(a, n_blocks, a.sig != nullptr, stream));
+    else if (recursive)
+        HIP_TRY(launch_branch(a, n_blocks, cam->path_samples, a.sig != nullptr, stream));
     else if (variant == MI_VARIANT_WAVEFRONT) {
         int rcw = render_tiles_wavefront(c, a, cam, wa, wf_batch, lds, d_compact, a.sig, range, stream);
         if (rcw != MI_OK) return rcw;

@@ -959,6 +959,113 @@ __global__ __launch_bounds__(kBlock) void pt_phong(K1Args A) {
     if (SIG && A.sig) A.sig[out_idx] = in_image ? sigsum : 0u;
 }
 
+// ---------------------------------------------------------------- path_samples > 1 (and the literal estimator)
+// Scene::shade_ray as written (tracing.rs:300-324): at every hit `path_samples` scattered rays are shaded
+// recursively and averaged.  No configuration uses path_samples != 1 (tracing.rs:370) and the tree grows as
+// path_samples^depth, so this is a completeness path, not a performance path: one lane per pixel, the recursion
+// unrolled onto an explicit per-lane stack (scratch memory), samples and random draws in the reference's
+// depth-first order.  The radiance is combined exactly as :316-321 nest it — ((brdf*incoming)*dot)/pdf,
+// /path_samples, emission + integral — so unlike the forward-accumulating kernels it reproduces the oracle's
+// f32 image bit for bit; MI_VARIANT_RECURSIVE runs it for path_samples == 1 too (tests use that as a
+// second, independent check of every device function).
+constexpr int kMaxRecursion = 64;
+struct BranchFrame {
+    Surf s;             // the hit being integrated over
+    f3 d;               // direction of the ray that produced it (scatter needs it)
+    f3 integral;        // :309
+    f3 brdf;            // of the sample whose incoming light is being computed
+    float dot_term, pdf;
+    uint32_t i;         // samples done at this level
+};
+
+template <bool SIG>
+__global__ __launch_bounds__(kBlock) void pt_branch(K1Args A, uint32_t path_samples) {
+    const DScene& S = A.S;
+    const DCamera& C = A.C;
+    Bvh<false> B;
+    bvh_bind(B, S, 0);
+    const uint32_t slot = blockIdx.x / kBlocksPerTile, sub = blockIdx.x % kBlocksPerTile;
+    const uint32_t tile = slot * (uint32_t)A.R.world + (uint32_t)A.R.rank;
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t in_x = wave * 8 + (lane & 7), in_y = sub * 8 + (lane >> 3);
+    const uint32_t out_idx = slot * kTilePixels + in_y * kTile + in_x;
+    uint32_t px = 0, py = 0;
+    bool in_image = false;
+    if (tile < A.R.tiles_total) {
+        px = (tile % A.R.tiles_x) * kTile + in_x;
+        py = (tile / A.R.tiles_x) * kTile + in_y;
+        in_image = (px < C.width) && (py < C.height);
+    }
+    const uint32_t pixel = py * C.width + px;
+    const float t_min = 0.001f, t_max = C.max_trace_dist;
+    const float PI = 3.14159265358979323846f;
+    const uint32_t depth_cap = C.path_depth < (uint32_t)kMaxRecursion ? C.path_depth : (uint32_t)kMaxRecursion;   // host checks <= 64
+    BranchFrame F[kMaxRecursion];
+    f3 accum = mk3(0.0f, 0.0f, 0.0f);
+    uint32_t sigsum = 0;
+    const uint32_t spp = in_image ? C.spp : 0u;
+    for (uint32_t sample = 0; sample < spp; sample++) {
+        Rng rng; f3 o, d;
+        rng_init(rng, A.seed_key, pixel, sample);
+        generate_ray(C, px, py, sample, rng, o, d);
+        uint32_t sig = 0;
+        uint32_t level = 0;
+        f3 ret = mk3(0.0f, 0.0f, 0.0f);
+        bool entering = true;                          // true: shade_ray(o, d, level) is being called; false: it returned `ret`
+        for (;;) {
+            if (entering) {
+                bool have_hit = false;
+                if (level >= depth_cap) {              // :301
+                    if (SIG) sig = sig_end_depth(sig);
+                } else {
+                    Best best;
+                    intersect_scene(S, B, o, d, t_min, t_max, rng, best);       // :305
+                    if (best.obj < 0) { if (SIG) sig = sig_end_miss(sig, rng); }
+                    else {
+                        if (SIG) sig = sig_hit(sig, best.t, best.obj);
+                        BranchFrame& f = F[level];
+                        resolve_hit(S, best, o, d, f.s);
+                        f.d = d; f.integral = mk3(0.0f, 0.0f, 0.0f); f.i = 0;
+                        have_hit = true;
+                    }
+                }
+                if (!have_hit) { ret = mk3(0.0f, 0.0f, 0.0f); entering = false; }   // background :302,306
+            } else {
+                if (level == 0) break;                 // shade_ray(camera ray, 0) returned
+                level--;
+                BranchFrame& f = F[level];             // :316  integral += (dot_term*(brdf (.) incoming)) / pdf
+                f.integral = mk3(f.integral.x + ((f.brdf.x * ret.x) * f.dot_term) / f.pdf,
+                                 f.integral.y + ((f.brdf.y * ret.y) * f.dot_term) / f.pdf,
+                                 f.integral.z + ((f.brdf.z * ret.z) * f.dot_term) / f.pdf);
+                f.i++;
+                entering = true;                       // fall into the sample loop of this level
+            }
+            if (entering) {
+                // here F[level] holds a hit; run the sample loop :310 from f.i
+                BranchFrame& f = F[level];
+                if (f.i < path_samples) {
+                    f3 nd; float inv_pdf;
+                    scatter_raw(f.s, f.d, rng, nd, f.brdf, inv_pdf);            // :312
+                    f.pdf = (inv_pdf != 1.0f) ? 1.0f / (2.0f * PI) : 1.0f;      // sample_hemisphere's pdf (materials.rs:178)
+                    f.dot_term = (mag2(f.s.n) > 0.0f) ? clampf(fabsf(dot(nd, f.s.n)), 0.0f, 1.0f) : 1.0f;   // :313
+                    o = f.s.p; d = nd; level++;        // :314 shade_ray(&new_ray, depth + 1)
+                } else {
+                    const float n = (float)path_samples;                        // :318, :321
+                    ret = mk3(f.s.emission.x + f.integral.x / n, f.s.emission.y + f.integral.y / n, f.s.emission.z + f.integral.z / n);
+                    entering = false;
+                }
+            }
+        }
+        accum = accum + ret;                                                    // :238
+        if (SIG) sigsum += sig;
+    }
+    float n = (float)C.spp;
+    float* o3 = A.out + (size_t)out_idx * 3;
+    if (in_image) { o3[0] = accum.x / n; o3[1] = accum.y / n; o3[2] = accum.z / n; }
+    else { o3[0] = 0.0f; o3[1] = 0.0f; o3[2] = 0.0f; }
+    if (SIG && A.sig) A.sig[out_idx] = in_image ? sigsum : 0u;
+}
+
 // ---------------------------------------------------------------- K1, voted state machine
 // The divergent part of the path is the BVH walk: a ray that enters the teapot takes
 // 20..150 node steps, its 63 neighbours take 0.  Running the walk to completion inside
@@ -1952,6 +2059,12 @@ hipError_t launch_phong(const K1Args& a, uint32_t n_blocks, bool sig, hipStream_
     dim3 grid(n_blocks), block(kBlock);
     if (sig) hipLaunchKernelGGL((pt_phong<true>), grid, block, 0, stream, a);
     else hipLaunchKernelGGL((pt_phong<false>), grid, block, 0, stream, a);
+    return hipGetLastError();
+}
+hipError_t launch_branch(const K1Args& a, uint32_t n_blocks, uint32_t path_samples, bool sig, hipStream_t stream) {
+    dim3 grid(n_blocks), block(kBlock);
+    if (sig) hipLaunchKernelGGL((pt_branch<true>), grid, block, 0, stream, a, path_samples);
+    else hipLaunchKernelGGL((pt_branch<false>), grid, block, 0, stream, a, path_samples);
     return hipGetLastError();
 }
 hipError_t launch_wf_main(const WfArgs& a, uint32_t n_blocks, bool sig, hipStream_t stream) {

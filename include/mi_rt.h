@@ -155,7 +155,7 @@ typedef struct mi_camera_desc {
     int32_t  projection_mode;
     int32_t  shading_mode;
     uint32_t path_depth;
-    uint32_t path_samples;      /* must be 1 on the GPU path (every config; tracing.rs:370) */
+    uint32_t path_samples;      /* 1 in every configuration (tracing.rs:370); != 1 runs MI_VARIANT_RECURSIVE */
     uint32_t screen_width;
     uint32_t screen_height;
     float    focal_length;
@@ -185,7 +185,9 @@ typedef enum mi_variant {
     MI_VARIANT_VOTED_DIAG = 4,  /* VOTED + per-phase trip / active-lane counters (never timed)      */
     MI_VARIANT_POOLED     = 5,  /* VOTED with two path slots per lane (one parked in L2); experimental, slower */
     MI_VARIANT_POOLED_DIAG = 6, /* POOLED + counters (never timed)                                  */
-    MI_VARIANT_WAVEFRONT  = 7   /* path state streamed through HBM, one kernel per phase (K1w); synchronises the stream */
+    MI_VARIANT_WAVEFRONT  = 7,  /* path state streamed through HBM, one kernel per phase (K1w); synchronises the stream */
+    MI_VARIANT_RECURSIVE  = 8   /* shade_ray as written (tracing.rs:300-324), recursion on a per-lane stack: the only variant for
+                                 * path_samples != 1 (chosen automatically); slow, bit-identical f32 image to the CPU restatement */
 } mi_variant;
 
 typedef struct mi_stats {

@@ -109,3 +109,38 @@ def test_phong_shading(gpu_ctx, orc, name):
 def test_phong_orthographic_ignores_variant(gpu_ctx, orc):
     sc = _mode(scenes.config2(75, 41, 9, 6), shading_mode=abi.MI_SHADE_PHONG, projection_mode=abi.MI_PROJ_ORTHOGRAPHIC)
     compare(gpu_ctx, orc, sc, seed=77, variant=abi.MI_VARIANT_VOTED)
+
+
+# ---- Scene::shade_ray as written: path_samples scattered rays per hit (tracing.rs:310-318) ----
+@pytest.mark.parametrize("name,path_samples", [("config1", 2), ("config2", 2), ("config2", 3), ("config5", 2), ("config4", 2)])
+def test_path_samples_greater_than_one(gpu_ctx, orc, name, path_samples):
+    """The library routes path_samples != 1 to the recursive estimator (MI_VARIANT_RECURSIVE).  It nests the
+    products exactly as the reference does, so the f32 image equals the oracle's bit for bit."""
+    sc = {"config1": lambda: scenes.config1(64, 64, 4, 4), "config2": lambda: scenes.config2(96, 64, 4, 4),
+          "config4": lambda: scenes.config4(64, 48, 4, 3, tex_size=64), "config5": lambda: scenes.config5(64, 48, 4, 5)}[name]()
+    sc.camera.path_samples = path_samples
+    flat = sc.flatten()
+    gpu_ctx.upload(flat)
+    f32, u8, sig, _ = gpu_ctx.render(sc.camera, seed=3, want_sig=True)
+    r32, r8, rsig, _ = orc.OracleScene(flat).render(sc.camera, seed=3)
+    assert np.array_equal(sig, rsig)
+    assert np.array_equal(f32, r32)
+    assert int(np.abs(u8.astype(int) - r8.astype(int)).max()) <= 1
+
+
+@pytest.mark.parametrize("name", ["config2", "config5", "head"])
+def test_recursive_estimator_is_bit_identical_to_the_oracle(gpu_ctx, orc, name):
+    """path_samples == 1 through MI_VARIANT_RECURSIVE: an independent check of every device function — not
+    only the decisions (signatures) but the f32 radiance itself, bit for bit — and of the forward-accumulating
+    default pipeline against it (same paths, radiance within the documented tolerance)."""
+    sc = {"config2": lambda: scenes.config2(160, 96, 16, 10), "config5": lambda: scenes.config5(96, 64, 16, 50),
+          "head": lambda: scenes.head_scene(64, 64, 4, 10)}[name]()
+    flat = sc.flatten()
+    gpu_ctx.upload(flat)
+    f32, _, sig, _ = gpu_ctx.render(sc.camera, seed=11, want_u8=False, want_sig=True, variant=abi.MI_VARIANT_RECURSIVE)
+    r32, _, rsig, _ = orc.OracleScene(flat).render(sc.camera, seed=11, want_u8=False)
+    assert np.array_equal(sig, rsig)
+    assert np.array_equal(f32, r32)
+    d32, _, dsig, _ = gpu_ctx.render(sc.camera, seed=11, want_u8=False, want_sig=True)
+    assert np.array_equal(dsig, sig)
+    assert float((np.abs(d32.astype(np.float64) - f32) / np.maximum(1.0, np.abs(f32))).max()) <= 2e-5

@@ -75,7 +75,7 @@ def test_error_paths(gpu_ctx):
     sc = scenes.config1(64, 64, 4, 4)
     gpu_ctx.upload(sc.flatten())
     cam = sc.camera
-    for field, value, code in (("path_samples", 2, abi.MI_ERR_UNSUPPORTED), ("shading_mode", 7, abi.MI_ERR_INVALID),
+    for field, value, code in (("path_samples", 0, abi.MI_ERR_INVALID), ("shading_mode", 7, abi.MI_ERR_INVALID),
                                ("projection_mode", -1, abi.MI_ERR_INVALID), ("aa_sample_count", 0, abi.MI_ERR_INVALID)):
         old = getattr(cam, field)
         setattr(cam, field, value)
