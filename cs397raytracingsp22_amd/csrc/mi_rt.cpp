@@ -170,7 +170,7 @@ extern "C" int mi_ctx_create(int device, mi_ctx** out) {
     if (const char* e = getenv("MI_RT_WF_PATHS")) c->wf_max_paths = (uint64_t)atoll(e);
     c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     HIP_TRY(hipMalloc((void**)&c->d_wf_cnt, (9 * 256 + 64) * sizeof(uint32_t)));
-    HIP_TRY(hipHostMalloc((void**)&c->h_hdr, 4 * sizeof(uint32_t), hipHostMallocMapped));
+    HIP_TRY(hipHostMalloc((void**)&c->h_hdr, 4 * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent));
     memset(c->h_hdr, 0, 4 * sizeof(uint32_t));
     HIP_TRY(hipHostGetDevicePointer((void**)&c->h_hdr_dev, c->h_hdr, 0));
     if (const char* e = getenv("MI_RT_LDS_PAD_KB")) c->lds_pad = (uint32_t)atoi(e) * 1024u;   // occupancy experiments
@@ -829,14 +829,20 @@ static int render_tiles_wavefront(mi_ctx* c, const K1Args& k, const mi_camera_de
     // teapot 15 KB -> 8 blocks per CU; 122.6 ms vs 126.0 ms for mode 1 on cfg2 1080p/256), 1 = nodes +
     // triangles (what the megakernels stage), 0 = everything from global memory
     const size_t node_bytes = (size_t)c->S.n_nodes * 32;
-    int trav_lds_mode = (c->S.n_meshes > 0 && node_bytes <= 64u * 1024u && !getenv("MI_RT_GLOBAL_BVH")) ? 2 : 0;
-    if (const char* e = getenv("MI_RT_WF_TRAV_LDS")) { int m = atoi(e); if (m == 0 || (m == 1 && lds) || (m == 2 && trav_lds_mode == 2)) trav_lds_mode = m; }
-    const size_t trav_lds_bytes = trav_lds_mode == 1 ? c->lds_bytes : (trav_lds_mode == 2 ? node_bytes : 0);
+    // 3 = nodes in LDS too, but they need most of a CU's 160 KB: ONE 1024-thread block per CU (16 waves)
+    int trav_lds_mode = 0;
+    if (c->S.n_meshes > 0 && !getenv("MI_RT_GLOBAL_BVH")) trav_lds_mode = node_bytes <= 64u * 1024u ? 2 : (node_bytes <= 156u * 1024u ? 3 : 0);
+    if (const char* e = getenv("MI_RT_WF_TRAV_LDS")) {
+        int m = atoi(e);
+        if (m == 0 || (m == 1 && lds) || (m == 2 && node_bytes <= 64u * 1024u) || (m == 3 && node_bytes <= 156u * 1024u)) trav_lds_mode = m;
+    }
+    const size_t trav_lds_bytes = trav_lds_mode == 1 ? c->lds_bytes : (trav_lds_mode >= 2 ? node_bytes : 0);
     a.R.lds_nodes = trav_lds_mode ? (uint32_t)c->S.n_nodes : 0;
     a.R.lds_tris = trav_lds_mode == 1 ? (uint32_t)c->S.n_tris : 0;
     float4* bufs[2] = { (float4*)c->d_wf_a, (float4*)c->d_wf_b };
     uint32_t trav_bpc = 6;                  // resident blocks per CU: bounded by LDS (160 KB) and by 8 waves/SIMD
     if (trav_lds_mode == 2) { trav_bpc = (uint32_t)((160u * 1024u) / (node_bytes ? node_bytes : 1)); if (trav_bpc > 8) trav_bpc = 8; if (trav_bpc < 2) trav_bpc = 2; }
+    if (trav_lds_mode == 3) trav_bpc = 1;
     if (const char* e = getenv("MI_RT_WF_TRAV_BPC")) trav_bpc = (uint32_t)atoi(e);
     const uint32_t trav_blocks = (uint32_t)c->n_cus * trav_bpc;
 

@@ -1774,8 +1774,10 @@ template <> struct TravBvh<1> { typedef Bvh<true> type; };
 template <> struct TravBvh<2> { typedef BvhNodesLds type; };
 __device__ __forceinline__ void bvh_bind(BvhNodesLds& B, const DScene& S, int) { B.nodes = k1_lds; B.tris = (cf4_ptr)S.tris; }
 
-template <int LDS>
-__global__ __launch_bounds__(kBlock, PT_TRAV_WAVES) void wf_trav(WfArgs A) {
+// BS: threads per block.  256 for the small-LDS modes; 1024 (one block per CU) when the node array needs most of a
+// CU's 160 KB of LDS (meshes of ~1-2.5 k triangles: the drone's 3471 nodes = 111 KB).
+template <int LDS, int BS>
+__global__ __launch_bounds__(BS, (BS == 256 ? PT_TRAV_WAVES : 4)) void wf_trav(WfArgs A) {
     const DScene& S = A.S;
     // Work distribution over the CONCATENATED queue (virtual indices; shard s owns [trav_pfx[s], trav_pfx[s+1])):
     // wave w owns chunk w outright, later chunks come from one shared cursor.  The static first chunk
@@ -1783,17 +1785,17 @@ __global__ __launch_bounds__(kBlock, PT_TRAV_WAVES) void wf_trav(WfArgs A) {
     // atomics retire at ~88 / us), 2.6 ms per frame and most of the multi-rank overhead; a queue that
     // the static chunks cover never touches the cursor at all.
     const uint32_t n_q = A.hdr[2];
-    const uint32_t n_waves = gridDim.x * (kBlock / 64u);
+    const uint32_t n_waves = gridDim.x * ((uint32_t)BS / 64u);
     const uint32_t chunk = 256u;          // 128 rays per grab: the cursor's round trip shows (trav x3); 1024: long tails (+5 %)
     const bool shared_part = n_waves * chunk < n_q;                  // anything beyond the static chunks?
-    if (blockIdx.x * (kBlock / 64u) * chunk >= n_q) return;       // nothing for this block (then nothing is left over either)
+    if (blockIdx.x * ((uint32_t)BS / 64u) * chunk >= n_q) return;       // nothing for this block (then nothing is left over either)
     typename TravBvh<LDS>::type B;
     if (LDS != 0) {
         cf4_ptr gn = (cf4_ptr)S.nodes;
         cf4_ptr gt = (cf4_ptr)S.tris;
         int nn = (int)A.R.lds_nodes * 2, nt = (LDS == 1) ? (int)A.R.lds_tris * 3 : 0;
-        for (int k = threadIdx.x; k < nn; k += kBlock) k1_lds[k] = gn[k];
-        for (int k = threadIdx.x; k < nt; k += kBlock) k1_lds[nn + k] = gt[k];
+        for (int k = threadIdx.x; k < nn; k += BS) k1_lds[k] = gn[k];
+        for (int k = threadIdx.x; k < nt; k += BS) k1_lds[nn + k] = gt[k];
         __syncthreads();
     }
     bvh_bind(B, S, (int)A.R.lds_nodes * 2);
@@ -1803,7 +1805,7 @@ __global__ __launch_bounds__(kBlock, PT_TRAV_WAVES) void wf_trav(WfArgs A) {
     const uint32_t lane = threadIdx.x & 63;
 
     // wave-uniform work cursor: a chunk [wnext, wend) of the queue
-    const uint32_t wave_id = blockIdx.x * (kBlock / 64u) + (threadIdx.x >> 6);
+    const uint32_t wave_id = blockIdx.x * ((uint32_t)BS / 64u) + (threadIdx.x >> 6);
     uint32_t wnext = wave_id * chunk, wend = min(wnext + chunk, n_q);
     bool drained = false;
     if (wnext >= n_q) { wnext = wend = 0; drained = true; }
@@ -2075,9 +2077,18 @@ hipError_t launch_wf_main(const WfArgs& a, uint32_t n_blocks, bool sig, hipStrea
 }
 hipError_t launch_wf_trav(const WfArgs& a, uint32_t n_blocks, int lds_mode, size_t lds_bytes, hipStream_t stream) {
     dim3 grid(n_blocks), block(kBlock);
-    if (lds_mode == 1) hipLaunchKernelGGL((wf_trav<1>), grid, block, lds_bytes, stream, a);
-    else if (lds_mode == 2) hipLaunchKernelGGL((wf_trav<2>), grid, block, lds_bytes, stream, a);
-    else hipLaunchKernelGGL((wf_trav<0>), grid, block, 0, stream, a);
+    if (lds_mode == 3) {           // nodes in LDS, one 1024-thread block per CU
+        static bool attr_set = false;
+        if (!attr_set) {           // > 64 KB of dynamic LDS needs the opt-in
+            hipError_t e = hipFuncSetAttribute((const void*)wf_trav<2, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((wf_trav<2, 1024>), grid, dim3(1024), lds_bytes, stream, a);
+    }
+    else if (lds_mode == 1) hipLaunchKernelGGL((wf_trav<1, 256>), grid, block, lds_bytes, stream, a);
+    else if (lds_mode == 2) hipLaunchKernelGGL((wf_trav<2, 256>), grid, block, lds_bytes, stream, a);
+    else hipLaunchKernelGGL((wf_trav<0, 256>), grid, block, 0, stream, a);
     return hipGetLastError();
 }
 hipError_t launch_wf_prefix(uint32_t* out_count, uint32_t* trav_count, uint32_t* in_count, uint32_t* in_blkpfx,
