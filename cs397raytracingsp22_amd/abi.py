@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libmi_rt.so")
 MI_TILE = 32
 
 # status codes (mi_status)
+MI_RT_ABI_VERSION = 2      # include/mi_rt.h
 MI_OK, MI_ERR_INVALID, MI_ERR_UNSUPPORTED, MI_ERR_NO_DEVICE, MI_ERR_HIP, MI_ERR_OOM, MI_ERR_NO_SCENE = 0, -1, -2, -3, -4, -5, -6
 # material kinds
 MI_MAT_LAMBERTIAN, MI_MAT_METAL, MI_MAT_DIELECTRIC, MI_MAT_PARAMETERIZED, MI_MAT_ISOTROPIC = range(5)

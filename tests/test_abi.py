@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     lib = abi.load()
     for name in declared_functions():
         assert hasattr(lib, name), name
-    assert lib.mi_abi_version() == 2
+    assert lib.mi_abi_version() == abi.MI_RT_ABI_VERSION == 2
 
 
 def test_ctypes_layout_matches_c(tmp_path):
@@ -68,3 +68,14 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h", ".hpp", ".sh")):
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "orc_" not in text and "liborc" not in text and "from oracle" not in text and "import oracle" not in text, f
+
+
+def test_abi_version_is_one_number_everywhere():
+    """include/mi_rt.h, the Python mirror, the library and __graft_entry__.build() agree."""
+    import re
+    from cs397raytracingsp22_amd import abi
+    hdr = open(os.path.join(ROOT, "include", "mi_rt.h")).read()
+    assert int(re.search(r"#define\s+MI_RT_ABI_VERSION\s+(\d+)", hdr).group(1)) == abi.MI_RT_ABI_VERSION
+    assert abi.load().mi_abi_version() == abi.MI_RT_ABI_VERSION
+    entry = open(os.path.join(ROOT, "__graft_entry__.py")).read()
+    assert "abi.MI_RT_ABI_VERSION" in entry            # build() checks against the mirror, not a literal
