@@ -1648,8 +1648,23 @@ __global__ __launch_bounds__(kBlock, PT_MAIN_WAVES) void wf_main(WfArgs A) {
     } else {
         // which (class, shard) range of st_in does this block read?  (binary search in the block prefix:
         // entries 0..S-1 = class A of each shard, S..2S-1 = class B)
-        uint32_t lo = 0, hi = 2u * (uint32_t)kWfShards;
-        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (A.in_blkpfx[mid] <= blockIdx.x) lo = mid; else hi = mid; }
+        // The shards of a class hold nearly equal counts, so interpolate and correct by a step or two (a binary
+        // search is nine DEPENDENT scalar loads, ~1.4k cycles at the head of every wave, before its state
+        // loads can even be issued).  Only the starting point is approximate; the walk is exact.
+        uint32_t lo;
+        {
+            const uint32_t b = blockIdx.x;
+            const uint32_t blocks_a = A.in_blkpfx[kWfShards], blocks_all = A.in_blkpfx[2 * kWfShards];
+            const bool in_b = b >= blocks_a;
+            const uint32_t base = in_b ? (uint32_t)kWfShards : 0u, first = in_b ? blocks_a : 0u;
+            const uint32_t span = in_b ? blocks_all - blocks_a : blocks_a;
+            uint32_t g = (uint32_t)((float)(b - first) * ((float)kWfShards / (float)(span ? span : 1u)));
+            g = base + (g < (uint32_t)kWfShards ? g : (uint32_t)kWfShards - 1u);
+            g = (uint32_t)__builtin_amdgcn_readfirstlane((int)g);
+            while (A.in_blkpfx[g] > b) g--;                    // in_blkpfx[0] = 0 <= b
+            while (A.in_blkpfx[g + 1] <= b) g++;               // in_blkpfx[2 S] = blocks_all > b
+            lo = g;
+        }
         WF_STAMP(1);
         const bool cls_b = lo >= (uint32_t)kWfShards;
         const uint32_t in_shard = cls_b ? lo - (uint32_t)kWfShards : lo;
