@@ -1,3 +1,2 @@
 #!/bin/bash
-for m in 3 0; do echo "RES mode=$m"; MI_RT_WF_TRAV_LDS=$m python tools/probe_cfgs.py cfg4; done
-timeout -k 10 600 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
+for b in 8 4 3; do echo "RES bpc=$b"; MI_RT_WF_TRAV_BPC=$b python tools/probe_overlap.py 2>&1 | grep sequential | tail -2; done
