@@ -549,8 +549,12 @@ __device__ __forceinline__ void test_object(OP ob, int idx, f3 o, f3 d, float t_
 // load, wave-uniform address) while the current one is tested.
 // `tag` (< 0) records which list loop produced the hit: -1 Triangle, -2 Sphere (Best.tri >= 0 is
 // reserved for mesh triangles); the wavefront pipeline uses it to class the path for free.
-__device__ __forceinline__ void consider_list(Best& b, bool ok, float t, int obj, int tag) {
-    bool take = ok & ((b.obj < 0) | (t < b.t) | ((t == b.t) & (obj < b.obj)));
+// `have` = "a hit is recorded" (b.obj >= 0), carried as a lane mask so that the whole decision stays in mask
+// registers (testing b.obj's sign bit made the compiler rebuild it from integers: 5 more VALU per object).
+__device__ __forceinline__ void consider_list(Best& b, bool& have, bool ok, float t, int obj, int tag) {
+    const bool better = (t < b.t) || ((t == b.t) && (obj < b.obj));
+    const bool take = ok && (!have || better);
+    have = have || take;
     b.t = take ? t : b.t;
     b.obj = take ? obj : b.obj;
     b.tri = take ? tag : b.tri;
@@ -558,6 +562,7 @@ __device__ __forceinline__ void consider_list(Best& b, bool ok, float t, int obj
 __device__ __forceinline__ void intersect_list(const DScene& S, f3 o, f3 d, float t_min, float t_max, Rng& rng, Best& best) {
     auto L = S.list;
     int k = 0;
+    bool have = best.obj >= 0;
     {   // Triangle::intersect_ray geometry.rs:431-450.  Two triangles per trip: the two
         // Moller-Trumbore chains (cross, dot, correctly rounded 1/g, ...) are independent, so the
         // in-order issue overlaps their latencies; `consider` is applied in list order.
@@ -567,14 +572,14 @@ __device__ __forceinline__ void intersect_list(const DScene& S, f3 o, f3 d, floa
             float t0, u0, v0, t1, u1, v1;
             bool ok0 = tri_t(o, d, ld3(r0->f), ld3(r0->f + 3), ld3(r0->f + 6), t_min, t_max, t0, u0, v0);
             bool ok1 = tri_t(o, d, ld3(r1->f), ld3(r1->f + 3), ld3(r1->f + 6), t_min, t_max, t1, u1, v1);
-            consider_list(best, ok0, t0, r0->index, -1);
-            consider_list(best, ok1, t1, r1->index, -1);
+            consider_list(best, have, ok0, t0, r0->index, -1);
+            consider_list(best, have, ok1, t1, r1->index, -1);
         }
         for (; k < end; k++) {
             auto r0 = &L[k];
             float t0, u0, v0;
             bool ok0 = tri_t(o, d, ld3(r0->f), ld3(r0->f + 3), ld3(r0->f + 6), t_min, t_max, t0, u0, v0);
-            consider_list(best, ok0, t0, r0->index, -1);
+            consider_list(best, have, ok0, t0, r0->index, -1);
         }
     }
     {   // Sphere::intersect_ray geometry.rs:395-413
@@ -583,7 +588,7 @@ __device__ __forceinline__ void intersect_list(const DScene& S, f3 o, f3 d, floa
             auto ob = &L[k];
             float t;
             bool ok = sphere_t(o, d, ld3(ob->f), ob->f[4], t_min, t_max, t);
-            consider_list(best, ok, t, ob->index, -2);
+            consider_list(best, have, ok, t, ob->index, -2);
         }
     }
     {   // Plane (geometry.rs:474-489) and ConvexVolume (geometry.rs:502-526): rare kinds, generic code
@@ -602,6 +607,7 @@ __device__ __forceinline__ void intersect_list(const DScene& S, f3 o, f3 d, floa
 __device__ __forceinline__ void intersect_list_masked(const DScene& S, unsigned long long mask, f3 o, f3 d,
                                                       float t_min, float t_max, Rng& rng, Best& best) {
     auto L = S.list;
+    bool have = best.obj >= 0;
     const int n_tri = S.n_list_tri, n_ts = S.n_list_tri + S.n_list_sphere;
     unsigned long long m = mask & ((n_ts >= 64) ? ~0ull : ((1ull << n_ts) - 1ull));
     while (m != 0ull) {
@@ -611,11 +617,11 @@ __device__ __forceinline__ void intersect_list_masked(const DScene& S, unsigned 
         if (k < n_tri) {
             float t0, u0, v0;
             bool ok0 = tri_t(o, d, ld3(r0->f), ld3(r0->f + 3), ld3(r0->f + 6), t_min, t_max, t0, u0, v0);
-            consider_list(best, ok0, t0, r0->index, -1);
+            consider_list(best, have, ok0, t0, r0->index, -1);
         } else {
             float t;
             bool ok = sphere_t(o, d, ld3(r0->f), r0->f[4], t_min, t_max, t);
-            consider_list(best, ok, t, r0->index, -2);
+            consider_list(best, have, ok, t, r0->index, -2);
         }
     }
     const int end = n_ts + S.n_list_plane + S.n_list_volume;
