@@ -82,3 +82,42 @@ def test_random_scene_parity(gpu_ctx, orc, seed):
         err = np.abs(f32[finite].astype(np.float64) - r32[finite])
         assert float((err / np.maximum(1.0, np.abs(r32[finite]))).max(initial=0.0)) <= 5e-5
         assert int(np.abs(u8.astype(int) - r8.astype(int)).max()) <= 1
+
+
+@pytest.mark.parametrize("seed", list(range(24)))
+def test_random_scene_random_modes(gpu_ctx, orc, seed):
+    """The same random scenes under random camera modes: skewed view / up, orthographic projection, Phong
+    shading, path_samples 2 and the recursive estimator (whose f32 image must equal the oracle's bit for bit)."""
+    rng = np.random.default_rng(7000 + seed)
+    sc = random_scene(2000 + seed)
+    cam = sc.camera
+    if rng.random() < 0.5:                                   # tilt / skew the basis (the reference never normalises it)
+        v = np.array([rng.uniform(-0.4, 0.4), rng.uniform(-0.4, 0.2), -1.0]) * rng.uniform(0.8, 1.3)
+        cam.view_dir = tuple(float(x) for x in v)
+        cam.up = tuple(float(x) for x in np.array([rng.uniform(-0.2, 0.2), 1.0, rng.uniform(-0.2, 0.2)]) * rng.uniform(0.9, 1.2))
+    mode = int(rng.integers(0, 5))
+    variant = abi.MI_VARIANT_DEFAULT
+    if mode == 0:
+        cam.projection_mode = abi.MI_PROJ_ORTHOGRAPHIC
+    elif mode == 1:
+        cam.shading_mode = abi.MI_SHADE_PHONG
+        sc.point_light_pos = tuple(float(x) for x in rng.uniform(-3, 3, 3) + np.array([0, 5, 2]))
+        sc.ambient = tuple(float(x) for x in rng.uniform(0, 0.3, 3))
+    elif mode == 2:
+        cam.path_samples = 2
+        cam.path_depth = min(cam.path_depth, 4)
+    elif mode == 3:
+        variant = abi.MI_VARIANT_RECURSIVE
+    flat = sc.flatten()
+    gpu_ctx.upload(flat)
+    r32, r8, rsig, _ = orc.OracleScene(flat).render(cam, seed=seed)
+    f32, u8, sig, _ = gpu_ctx.render(cam, seed=seed, want_sig=True, variant=variant)
+    assert np.array_equal(sig, rsig), f"seed {seed} mode {mode}"
+    finite = np.isfinite(r32)
+    assert np.array_equal(np.isfinite(f32), finite)
+    if mode in (1, 2, 3):                                    # literal estimators: same arithmetic, same bits
+        assert np.array_equal(f32[finite], r32[finite]), f"seed {seed} mode {mode}"
+    else:
+        err = np.abs(f32[finite].astype(np.float64) - r32[finite])
+        assert float((err / np.maximum(1.0, np.abs(r32[finite]))).max(initial=0.0)) <= 5e-5
+    assert int(np.abs(u8.astype(int) - r8.astype(int)).max()) <= 1
