@@ -1774,7 +1774,8 @@ __global__ __launch_bounds__(kBlock, PT_MAIN_WAVES) void wf_main(WfArgs A) {
         A.st_out[3 * (size_t)cap + pos] = make_float4(__uint_as_float(P.rng.s0), __uint_as_float(P.rng.s1), __uint_as_float(pix),
                                                       __uint_as_float((sample & 0xffffu) | (P.depth << 16)));
         A.st_out[4 * (size_t)cap + pos] = make_float4(__uint_as_float(P.sig), best.t, __int_as_float(best.obj), __int_as_float(best.tri));
-        if (enters) A.st_out[5 * (size_t)cap + pos] = make_float4(0.0f, 0.0f, __int_as_float(tm), 0.0f);   // plane 5 only for mesh rays
+        // plane 5: which mesh the walk starts with — only worth 32 bytes of traffic when there is more than one
+        if (enters && S.n_meshes > 1) A.st_out[5 * (size_t)cap + pos] = make_float4(0.0f, 0.0f, __int_as_float(tm), 0.0f);
     }
     if (alive && enters) A.trav_q[(size_t)out_shard * A.region + qpos] = (uint32_t)pos;
 #ifdef PT_WF_STAMPS
@@ -1862,10 +1863,11 @@ __global__ __launch_bounds__(BS, (BS == 256 ? PT_TRAV_WAVES : 4)) void wf_trav(W
                 while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (A.trav_pfx[mid] <= vi) lo = mid; else hi = mid; }
                 pos = A.trav_q[(size_t)lo * A.region + (vi - A.trav_pfx[lo])];
                 const float4 q0 = A.st_out[0 * (size_t)cap + pos], q1 = A.st_out[1 * (size_t)cap + pos];
-                const float4 q4 = A.st_out[4 * (size_t)cap + pos], q5 = A.st_out[5 * (size_t)cap + pos];
+                const float4 q4 = A.st_out[4 * (size_t)cap + pos];
                 o = mk3(q0.x, q0.y, q0.z); d = mk3(q0.w, q1.x, q1.y);
                 best.t = q4.y; best.obj = __float_as_int(q4.z); best.tri = -1; best.u = 0.0f; best.v = 0.0f;
-                tm = __float_as_int(q5.z);
+                tm = 0;                                  // one mesh: the ray entered it
+                if (S.n_meshes > 1) tm = __float_as_int(A.st_out[5 * (size_t)cap + pos].z);
                 // the root test of mesh tm passed in wf_main; redo the set-up (same arithmetic)
                 (void)enter_next_mesh(S, B, tm, o, d, t_min, t_max, too, tod, tinv, ti, tend, ttb);
                 tbt = t_max; tbtri = -1; tbu = tbv = 0.0f;
