@@ -121,3 +121,33 @@ def test_eye_in_the_plane_of_a_large_triangle(gpu_ctx, orc, height):
     _, _, sig, _ = gpu_ctx.render(cam, seed=5, want_u8=False, want_sig=True)
     _, _, rsig, _ = orc.OracleScene(flat).render(cam, seed=5, want_u8=False)
     assert np.array_equal(sig, rsig)
+
+
+@pytest.mark.parametrize("name", ["config2", "config4", "config5"])
+def test_every_tile_of_the_full_frames(gpu_ctx, name):
+    """All 2040 tiles of the 1080p frames (the oracle windows of the other tests cover a handful): the masked
+    render equals the unmasked one, signatures and radiance, bit for bit."""
+    sc = {"config2": lambda: scenes.config2(1920, 1080, 16, 10), "config4": lambda: scenes.config4(1920, 1080, 4, 10, tex_size=256),
+          "config5": lambda: scenes.config5(1920, 1080, 16, 50)}[name]()
+    gpu_ctx.upload(sc.flatten())
+    f32, _, sig, _ = gpu_ctx.render(sc.camera, seed=21, want_u8=False, want_sig=True)
+    fast, _, _, _ = gpu_ctx.render(sc.camera, seed=21, want_u8=False, want_sig=False)     # dead-tile shortcut live
+    os.environ["MI_RT_NO_TILE_MASK"] = "1"
+    try:
+        g32, _, gsig, _ = gpu_ctx.render(sc.camera, seed=21, want_u8=False, want_sig=True)
+    finally:
+        del os.environ["MI_RT_NO_TILE_MASK"]
+    assert np.array_equal(gsig, sig) and np.array_equal(g32, f32) and np.array_equal(fast, f32)
+    assert int((sig != 0).sum()) > 0
+
+
+def test_full_frame_against_the_recursive_kernel(gpu_ctx):
+    """The same frame through two unrelated kernels — the masked wavefront pipeline and the one-lane-per-pixel
+    recursive estimator (no masks, no compaction, no queues): every pixel of 1080p takes the same paths."""
+    from cs397raytracingsp22_amd import abi
+    sc = scenes.config2(1920, 1080, 4, 10)
+    gpu_ctx.upload(sc.flatten())
+    f32, _, sig, _ = gpu_ctx.render(sc.camera, seed=8, want_u8=False, want_sig=True)
+    r32, _, rsig, _ = gpu_ctx.render(sc.camera, seed=8, want_u8=False, want_sig=True, variant=abi.MI_VARIANT_RECURSIVE)
+    assert np.array_equal(sig, rsig)
+    assert float((np.abs(f32.astype(np.float64) - r32) / np.maximum(1.0, np.abs(r32))).max()) <= 2e-5
