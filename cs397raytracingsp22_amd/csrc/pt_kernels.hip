@@ -1636,7 +1636,7 @@ __global__ __launch_bounds__(kBlock, PT_MAIN_WAVES) void wf_main(WfArgs A) {
         if (!SIG && (mesh_word >> 63)) {
             // nothing is reachable from this tile: every sample is the black background (tracing.rs:306).
             // (With signatures on the rays are still generated: the signature folds in the RNG state.)
-            if (valid) A.samp[(size_t)(i / A.npix) * A.npix + (i % A.npix)] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            // wf_reduce knows the same masks and does not read these slots, so nothing is written at all
             return;
         }
         alive = valid;
@@ -1979,7 +1979,13 @@ __global__ __launch_bounds__(256) void wf_reduce(WfArgs A, uint32_t first_batch,
     if (pix >= A.npix) return;
     float4 acc = first_batch ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : A.accum[pix];
     uint32_t sigsum = __float_as_uint(acc.w);
-    for (uint32_t s = 0; s < A.s_count; s++) {
+    // dead tile (nothing reachable, wf_main generated no ray and wrote no sample): every sample is +0.0
+    bool dead = false;
+    if (A.tile_mask && !A.sig) {
+        const uint32_t tile = (pix / kTilePixels) * (uint32_t)A.R.world + (uint32_t)A.R.rank;
+        dead = tile < A.R.tiles_total && (A.tile_mask[A.R.tiles_total + tile] >> 63) != 0ull;
+    }
+    for (uint32_t s = 0; s < (dead ? 0u : A.s_count); s++) {
         const float4 v = A.samp[(size_t)s * A.npix + pix];
         acc.x = acc.x + v.x; acc.y = acc.y + v.y; acc.z = acc.z + v.z;      // final_color += shade_ray(..)  :238
         sigsum += __float_as_uint(v.w);
