@@ -40,8 +40,15 @@ def usable_cores():
 
 def build(force=False):
     """Compile the oracle with gcc (oracle/Makefile)."""
-    if force or not os.path.exists(LIB_PATH):
+    # always ask make: it rebuilds when a source or include/mi_rt.h is newer than the library (an ABI change
+    # must never meet a stale oracle) and does nothing otherwise
+    if os.environ.get("ORC_LIB"):
+        return
+    try:
         subprocess.run(["make", "-C", _HERE] + (["-B"] if force else []), check=True, capture_output=True)
+    except (OSError, subprocess.CalledProcessError):
+        if not os.path.exists(LIB_PATH):
+            raise
 
 
 _lib = None
