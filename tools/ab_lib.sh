@@ -13,4 +13,4 @@ for i in range(4):
 print("%.1f ms" % best[0], {k: round(v,1) for k,v in best[1].items()})
 PY
 )"; }
-for rep in 1 2; do for e in "$@"; do run "$e"; done; done
+for rep in 1 2 3 4; do for e in "$@"; do run "$e"; done; done
