@@ -176,7 +176,7 @@ struct K1Args {
 // ---- wavefront pipeline (pt_kernels.hip "K1w") ----
 // Path state streamed through HBM as 6 float4 planes [6][cap] (coalesced 16-byte accesses):
 //   q0 o.xyz d.x | q1 d.yz T.xy | q2 T.z L.xyz | q3 rng.s0 rng.s1 pix sample|depth<<16
-//   plane-4 array: 12-byte hit records {t, obj, tri} packed, then cap 4-byte signature words | q5 best.u best.v mesh
+//   plane-4 array: packed sub-arrays {t, obj} 8 B x cap | tri 4 B x cap (class B only) | signature 4 B x cap; q5 best.u best.v mesh
 constexpr int kWfPlanes = 6;
 // Appends are SHARDED: block b of wf_main appends its survivors to region (b % kWfShards) of
 // st_out with that shard's own counter, so no single address sees more than ~1/256 of the

@@ -1577,11 +1577,13 @@ __global__ __launch_bounds__(kBlock, PT_MIN_WAVES) void pt_megakernel_pooled(K1A
 // index of (plane p, path slot k) in the path-state buffer: plain SoA planes.  (Groups of 64 slots with their
 // planes adjacent — [k / 64][p][k % 64], one wave's accesses inside 6 KB — measured the same: 105.9 vs 106.0 ms.)
 __device__ __forceinline__ size_t st_idx(int p, size_t k, uint32_t cap) { return (size_t)p * (size_t)cap + k; }
-// The hit record (t, obj, tri) is 12 bytes: it lives packed at the start of the plane-4 array, and the running
-// signature (diagnostic, 4 bytes) behind it — 76 instead of 80 bytes per path and direction when signatures are off.
-struct HitRec { float t; int obj; int tri; };
-__device__ __forceinline__ HitRec* st_hit(float4* st, size_t k, uint32_t cap) { return (HitRec*)(st + st_idx(4, 0, cap)) + k; }
-__device__ __forceinline__ uint32_t* st_sig(float4* st, size_t k, uint32_t cap) { return (uint32_t*)((HitRec*)(st + st_idx(4, 0, cap)) + cap) + k; }
+// The hit record lives in the plane-4 array as three packed sub-arrays: {t, obj} (8 bytes, every path), tri (4 bytes,
+// class B only: a class-A path's hit is a plain Triangle / Plane, tri = -1 by construction) and the running
+// signature (4 bytes, diagnostic): 72 bytes per class-A path and direction instead of 80.
+struct Hit2 { float t; int obj; };
+__device__ __forceinline__ Hit2* st_hit(float4* st, size_t k, uint32_t cap) { return (Hit2*)(st + st_idx(4, 0, cap)) + k; }
+__device__ __forceinline__ int* st_tri(float4* st, size_t k, uint32_t cap) { return (int*)((Hit2*)(st + st_idx(4, 0, cap)) + cap) + k; }
+__device__ __forceinline__ uint32_t* st_sig(float4* st, size_t k, uint32_t cap) { return (uint32_t*)((Hit2*)(st + st_idx(4, 0, cap)) + cap) + cap + k; }
 __device__ __forceinline__ uint32_t wf_append(uint32_t* counter, bool want) {
     const unsigned long long m = __builtin_amdgcn_ballot_w64(want);
     uint32_t base = 0;
@@ -1690,7 +1692,8 @@ __global__ __launch_bounds__(kBlock, PT_MAIN_WAVES) void wf_main(WfArgs A) {
         // ---- Scene::shade_ray, one level (tracing.rs:305-321), for the hit of the previous iteration ----
         const float4 q0 = A.st_in[st_idx(0, k, cap)], q1 = A.st_in[st_idx(1, k, cap)], q2 = A.st_in[st_idx(2, k, cap)];
         const float4 q3 = A.st_in[st_idx(3, k, cap)];
-        const HitRec hr = *st_hit(A.st_in, k, cap);
+        const Hit2 hr = *st_hit(A.st_in, k, cap);
+        const int hr_tri = cls_b ? *st_tri(A.st_in, k, cap) : -1;       // wave-uniform choice: class-A blocks never touch the array
         P.o = mk3(q0.x, q0.y, q0.z); P.d = mk3(q0.w, q1.x, q1.y); P.T = mk3(q1.z, q1.w, q2.x); P.L = mk3(q2.y, q2.z, q2.w);
         P.rng.s0 = __float_as_uint(q3.x); P.rng.s1 = __float_as_uint(q3.y);
         pix = __float_as_uint(q3.z);
@@ -1698,7 +1701,7 @@ __global__ __launch_bounds__(kBlock, PT_MAIN_WAVES) void wf_main(WfArgs A) {
         sample = sd & 0xffffu; P.depth = sd >> 16;
         P.sig = 0;
         if (SIG) P.sig = *st_sig(A.st_in, k, cap);
-        best.t = hr.t; best.obj = hr.obj; best.tri = hr.tri; best.u = 0.0f; best.v = 0.0f;
+        best.t = hr.t; best.obj = hr.obj; best.tri = hr_tri; best.u = 0.0f; best.v = 0.0f;
         if (valid && best.tri >= 0) {       // plane 5 (barycentrics) exists only for mesh hits
             const float4 q5 = A.st_in[st_idx(5, k, cap)];
             best.u = q5.x; best.v = q5.y;
@@ -1783,7 +1786,8 @@ __global__ __launch_bounds__(kBlock, PT_MAIN_WAVES) void wf_main(WfArgs A) {
         A.st_out[st_idx(2, pos, cap)] = make_float4(P.T.z, P.L.x, P.L.y, P.L.z);
         A.st_out[st_idx(3, pos, cap)] = make_float4(__uint_as_float(P.rng.s0), __uint_as_float(P.rng.s1), __uint_as_float(pix),
                                                       __uint_as_float((sample & 0xffffu) | (P.depth << 16)));
-        { HitRec hw; hw.t = best.t; hw.obj = best.obj; hw.tri = best.tri; *st_hit(A.st_out, pos, cap) = hw; }
+        { Hit2 hw; hw.t = best.t; hw.obj = best.obj; *st_hit(A.st_out, pos, cap) = hw; }
+        if (!cls_a) *st_tri(A.st_out, pos, cap) = best.tri;
         if (SIG) *st_sig(A.st_out, pos, cap) = P.sig;
         // plane 5: which mesh the walk starts with — only worth 32 bytes of traffic when there is more than one
         if (enters && S.n_meshes > 1) A.st_out[st_idx(5, pos, cap)] = make_float4(0.0f, 0.0f, __int_as_float(tm), 0.0f);
@@ -1874,7 +1878,7 @@ __global__ __launch_bounds__(BS, (BS == 256 ? PT_TRAV_WAVES : 4)) void wf_trav(W
                 while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (A.trav_pfx[mid] <= vi) lo = mid; else hi = mid; }
                 pos = A.trav_q[(size_t)lo * A.region + (vi - A.trav_pfx[lo])];
                 const float4 q0 = A.st_out[st_idx(0, pos, cap)], q1 = A.st_out[st_idx(1, pos, cap)];
-                const HitRec hr = *st_hit(A.st_out, pos, cap);
+                const Hit2 hr = *st_hit(A.st_out, pos, cap);
                 o = mk3(q0.x, q0.y, q0.z); d = mk3(q0.w, q1.x, q1.y);
                 best.t = hr.t; best.obj = hr.obj; best.tri = -1; best.u = 0.0f; best.v = 0.0f;
                 tm = 0;                                  // one mesh: the ray entered it
@@ -1928,8 +1932,9 @@ __global__ __launch_bounds__(BS, (BS == 256 ? PT_TRAV_WAVES : 4)) void wf_trav(W
                 // StaticMesh results merged: hand the closest hit back to the path.  70 % of the rays that enter
                 // a root box hit no triangle closer than the list's hit: their record is already right.
                 if (best.tri >= 0) {
-                    HitRec hw; hw.t = best.t; hw.obj = best.obj; hw.tri = best.tri;
+                    Hit2 hw; hw.t = best.t; hw.obj = best.obj;
                     *st_hit(A.st_out, pos, cap) = hw;                 // the signature has its own words: no read-modify-write
+                    *st_tri(A.st_out, pos, cap) = best.tri;
                     A.st_out[st_idx(5, pos, cap)] = make_float4(best.u, best.v, 0.0f, 0.0f);
                 }
                 have = false;
