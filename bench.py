@@ -7,15 +7,23 @@
 
 A "step" is one pass of the hot path over one frame: K1w (the wavefront path-tracing
 pipeline over this rank's tiles: wf_main / wf_trav once per path segment + wf_reduce) -> the
-frame's single gather (RCCL over xGMI, N > 1 only) -> K3 un-permute -> K4 tone-map on rank 0.  Workload = BASELINE.json configs[1]: Cornell box + Utah teapot
-BVH, 1920x1080, 256 spp, path_depth 10, synthetic scene built from the reference's
-primitive types (cs397raytracingsp22_amd/scenes.py).  The SAME frame is rendered at every
-N (tiles sharded over ranks), so scaling is "strong"; `value` = W*H*spp / step time,
-whole job, scene and all buffers resident in HBM before the timed region.
+frame's single gather (RCCL over xGMI, N > 1 only) -> K3 un-permute -> K4 tone-map on rank 0.
+Default workload = BASELINE.json configs[1]: Cornell box + Utah teapot BVH, 1920x1080, 256 spp,
+path_depth 10, synthetic scene built from the reference's primitive types
+(cs397raytracingsp22_amd/scenes.py); --config selects another BASELINE configuration.  The SAME
+frame is rendered at every N (tiles sharded over ranks), so scaling is "strong"; `value` =
+W*H*spp / step time, whole job, scene and all buffers resident in HBM before the timed region.
 
-Rank 0 prints ONE JSON line with `roofline` and (N = 1) `cpu_baseline` objects.
+Rank 0 prints ONE JSON line.  `roofline` is the HBM roofline of the pipeline: achieved = HBM bytes per frame /
+pipeline time, never the "logical" bytes of SURVEY.md 8(d) (those are served from SGPRs / LDS and
+exceed what HBM could deliver; they are printed as `algorithmic_bytes_per_sample`, informational).
+HBM bytes come from the rocprofv3 PMC passes committed under profiles/ WHEN they were measured on the
+kernel sources of this checkout (source hash), otherwise from the traffic model evaluated on this run's
+own path counts (mi_last_pipeline_counts); `traffic_source` says which.  `roofline.valu` is the
+second bound of this VALU-heavy path (issue utilisation and live lanes, committed PMC only).
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -24,13 +32,52 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (about 6.3 TB/s achievable)
+KERNEL_SOURCES = ["cs397raytracingsp22_amd/csrc/pt_kernels.hip", "cs397raytracingsp22_amd/csrc/pt_device.h",
+                  "cs397raytracingsp22_amd/csrc/mi_rt.cpp"]
+
+CONFIGS = {   # name: (scene factory, workload text, workcounts file key, BASELINE.json metric config?)
+    "cfg1": "configs[0] Cornell box (10 Triangle + 2 Sphere), 400x400, 16 spp, depth 8",
+    "cfg2": "configs[1] Cornell box (10 Triangle + 2 Sphere) + teapot StaticMesh (240 tris, reference-topology BVH), 1920x1080, 256 spp",
+    "cfg3": "configs[2] same scene, 1920x1080, 1024 spp (the 8-GPU tiling configuration)",
+    "cfg4": "configs[3] textured drone StaticMesh (1736 tris, five synthetic 2048^2 maps incl. normal map) in the Cornell box, 1920x1080, 256 spp",
+    "cfg5": "configs[4] dielectric sphere enclosing an isotropic ConvexVolume + glass + metal, 1920x1080, 4096 spp, depth 50",
+    "head": "the reference's own run() scene (tracing.rs:356-543: drone + cube + 32512-triangle sphere meshes, 15 ParameterizedMaterial "
+            "spheres, 2 volumes, plane, light) at the published 800x800, 256 spp",
+}
+
+
+def make_scene(name):
+    from cs397raytracingsp22_amd import scenes
+    if name == "cfg1":
+        return scenes.config1()
+    if name == "cfg2":
+        return scenes.config2()
+    if name == "cfg3":
+        return scenes.config3()
+    if name == "cfg4":
+        return scenes.config4()
+    if name == "cfg5":
+        return scenes.config5()
+    return scenes.head_scene(800, 800, 256, 10, textures=scenes.load_asset_textures())
+
+
+def source_hash():
+    h = hashlib.sha1()
+    for f in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:12]
 
 
 def algorithmic_bytes_per_sample(cfg: str, spp: int):
     """B_sample = S*B_list + N_box*32 + N_tri*36 + N_meshhit*60 + N_texel*3 + 12/spp,
-    with the per-sample counters measured by the CPU oracle (tests/golden/workcounts_<cfg>.json)."""
-    with open(os.path.join(ROOT, "tests", "golden", f"workcounts_{cfg}.json")) as fh:
+    with the per-sample counters measured by the CPU oracle (tests/golden/workcounts_<cfg>.json).
+    LOGICAL bytes (what traversal dereferences, cache-less): informational, never a roofline numerator."""
+    path = os.path.join(ROOT, "tests", "golden", f"workcounts_{'cfg2' if cfg == 'cfg3' else cfg}.json")
+    if not os.path.exists(path):
+        return None, None
+    with open(path) as fh:
         wc = json.load(fh)
     p = wc["per_sample"]
     b = (p["segments"] * wc["b_list_bytes"] + p["box_tests"] * 32.0 + p["tri_tests"] * 36.0 +
@@ -38,40 +85,69 @@ def algorithmic_bytes_per_sample(cfg: str, spp: int):
     return b, p["segments"]
 
 
-def measured_traffic(cfg: str):
-    """HBM bytes per K1 launch from the rocprofv3 PMC passes committed under profiles/
-    (FETCH_SIZE and WRITE_SIZE in separate passes, gfx950 read correction applied), or None."""
+def committed_pmc(cfg: str):
+    """profiles/traffic_<cfg>.json (tools/prof.sh + tools/prof_json.py) if it was measured on THESE kernel sources."""
     path = os.path.join(ROOT, "profiles", f"traffic_{cfg}.json")
     if not os.path.exists(path):
-        return None
+        return None, "no committed PMC profile for this configuration"
     with open(path) as fh:
-        return json.load(fh).get("hbm_bytes_per_launch")
+        t = json.load(fh)
+    if t.get("source_hash") != source_hash():
+        return None, f"committed PMC profile {t.get('tag')} was measured on other kernel sources ({t.get('source_hash')} != {source_hash()})"
+    return t, None
+
+
+def traffic_model(counts, n_meshes):
+    """HBM bytes of one pipeline pass from this run's own path counts: every path that
+    survives a pass is written once and read once (72 B class A, 76 B class B), a queued ray costs its queue word
+    (4 B written + 4 B read) and the walker's fetch of origin, direction and hit record (40 B), every sample
+    slot is written once and read once by wf_reduce (16 B each), and the frame leaves as 16 B accumulator +
+    12 B compact pixel.  An upper bound: the samples of dead tiles are neither written nor read."""
+    state = 2 * (counts["paths_a"] * 72 + counts["paths_b"] * 76)
+    queue = counts["queue_entries"] * (8 + 40 + (16 if n_meshes > 1 else 0))
+    samp = counts["sample_slots"] * 32
+    fb = counts["pixels"] * 28
+    return float(state + queue + samp + fb)
 
 
 def cpu_baseline(sc, flat):
-    """The plain-C oracle (a port: the Rust reference cannot be built here) timed on this
-    host's cores on a bounded sample of the same workload."""
+    """The plain-C oracle (a port: the Rust reference cannot be built here) timed on this host's cores on a
+    bounded sample of the same workload: built -O3 -march=native on this host, one task
+    per scanline like rayon (tracing.rs:228), every usable core."""
     from oracle import orc_py
     cam = sc.camera
-    threads = min(orc_py.usable_cores(), 64)
-    o = orc_py.OracleScene(flat)
+    threads = orc_py.usable_cores()
+    build = "-O3 -march=native"
+    try:
+        lib = orc_py.load(orc_py.build_native())
+    except Exception as e:      # no compiler on this host: the portable -O2 build, and say so
+        lib, build = None, f"-O2 portable (native build failed: {type(e).__name__})"
+    o = orc_py.OracleScene(flat, lib=lib)
     W, H = cam.screen_width, cam.screen_height
-    # rows are the parallel unit (tracing.rs:228).  Time-boxed: successive sets of `threads` rows,
-    # each set spread evenly over the whole image height (same mix of cheap and expensive pixels),
-    # until ~12 s of CPU work have been done.
-    rows_per_set = max(4 * threads, 32)          # several rows per worker: the dynamic row queue balances them
+    # Time-boxed: successive sets of rows, each set spread evenly over the image height (same mix of cheap and
+    # expensive pixels as the whole frame), until about 5 s of CPU work have been done.
+    rows_per_set = max(2 * threads, 16)
     stride = max(1, H // rows_per_set)
     rows_per_set = min(rows_per_set, H // stride)
     n, sets, dt = 0, 0, 0.0
-    while dt < 12.0 and sets < stride:
+    while dt < 5.0 and sets < stride:
         t0 = time.perf_counter()
         o.render(cam, seed=1, threads=threads, window=(0, sets, W, rows_per_set), row_stride=stride,
                  want_u8=False, want_sig=False)
         dt += time.perf_counter() - t0
         n += W * rows_per_set * cam.aa_sample_count
         sets += 1
+    model = "unknown CPU"
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
     rows = rows_per_set * sets
-    return {"value": n / dt / 1e6, "unit": "Msamples/s", "cores": threads, "kind": "port",
+    return {"value": n / dt / 1e6, "unit": "Msamples/s", "cores": threads, "kind": "port", "cpu": model, "build": build,
             "sample": f"{rows} full-width rows ({sets} sets of every {stride}th row) of the same {W}x{H} frame, all {cam.aa_sample_count} spp: "
                       f"{n} samples in {dt:.1f} s (plain-C oracle, one task per scanline like rayon, tracing.rs:228)"}
 
@@ -81,9 +157,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", default="cfg2", choices=["cfg1", "cfg2", "cfg3"])
+    ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
     ap.add_argument("--spp", type=int, default=0, help="override samples per pixel (debug; invalidates the metric)")
     ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--flags", type=int, default=0, help="mi_render_opts.flags (MI_OPT_*), developer A/B")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     ap.add_argument("--same-gpu", action="store_true", help="rehearsal: every rank uses GPU 0 (with --backend gloo)")
@@ -91,7 +168,7 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from cs397raytracingsp22_amd import Context, scenes
+    from cs397raytracingsp22_amd import Context
     from cs397raytracingsp22_amd.dist import TiledRenderer
 
     rank = int(os.environ.get("RANK", "0"))
@@ -110,19 +187,14 @@ def main():
         else:
             dist.init_process_group(backend=args.backend)
 
-    if args.config == "cfg1":
-        sc, cfgname = scenes.config1(), "cfg1"
-    elif args.config == "cfg3":
-        sc, cfgname = scenes.config3(), "cfg2"
-    else:
-        sc, cfgname = scenes.config2(), "cfg2"
+    sc = make_scene(args.config)
     if args.spp:
         sc.camera.aa_sample_count = args.spp
     cam = sc.camera
     flat = sc.flatten()
     ctx = Context(local_rank)
     ctx.upload(flat)                      # scene resident in HBM before the timed region
-    r = TiledRenderer(ctx, cam, rank=rank, world=world, device=str(device), variant=args.variant)
+    r = TiledRenderer(ctx, cam, rank=rank, world=world, device=str(device), variant=args.variant, flags=args.flags)
 
     def barrier():
         if world > 1:
@@ -134,10 +206,12 @@ def main():
     barrier()
     t0 = time.perf_counter()
     pipe = {"wf_main_ms": 0.0, "wf_trav_ms": 0.0, "wf_reduce_ms": 0.0, "launches": 0}
+    counts = None
     for s in range(args.steps):
         r.render_frame(seed=1 + s, time_kernel=True)
         for k, v in ctx.last_pipeline_ms().items():
             pipe[k] += v
+        counts = ctx.last_pipeline_counts()
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -155,37 +229,55 @@ def main():
     value = samples_per_frame * args.steps / dt / 1e6
 
     if rank == 0:
-        b_sample, segs = algorithmic_bytes_per_sample(cfgname, cam.aa_sample_count)
-        # dominant kernel = K1w, the wavefront pipeline: one pipeline pass traces this rank's share of
-        # the frame (kernel_ms = HIP events around the whole pass; per-kernel sums from events around
-        # every launch).  The megakernel variants (--variant 1..6) are a single launch.
-        samples_per_launch = samples_per_frame / world
-        achieved = b_sample * samples_per_launch / (kernel_ms * 1e-3) / 1e9
+        b_sample, segs = algorithmic_bytes_per_sample(args.config, cam.aa_sample_count)
+        wavefront = args.variant in (0, 7)
         per_step = {k: (v / args.steps) for k, v in pipe.items()}
-        traffic = measured_traffic(cfgname) if world == 1 and not args.spp else None
+        # ---- HBM roofline of the dominant kernel group (the pipeline pass of this rank) ----
+        pmc, why_not = (committed_pmc(args.config) if world == 1 and not args.spp and wavefront and not args.flags else (None, "not the profiled configuration"))
+        model_bytes = traffic_model(counts, flat.desc.n_meshes) if (wavefront and counts and counts["passes"]) else None
+        if pmc is not None and pmc.get("hbm_bytes_per_launch"):
+            traffic, traffic_source = float(pmc["hbm_bytes_per_launch"]), \
+                f"committed rocprofv3 PMC, profiles/traffic_{args.config}.json tag {pmc['tag']} (same kernel sources {pmc['source_hash']}); not measured in this run"
+        elif model_bytes is not None:
+            traffic, traffic_source = model_bytes, f"traffic model on this run's own path counts ({why_not})"
+        else:
+            traffic, traffic_source = None, why_not
+        achieved = traffic / (kernel_ms * 1e-3) / 1e9 if traffic else None
+        frac = achieved / HBM_PEAK_GBS if achieved is not None else None
+        if frac is not None:
+            assert frac <= 1.0, f"HBM roofline fraction {frac} > 1: traffic accounting is wrong"
+        valu = None
+        if pmc is not None:
+            valu = {k: {"ms": v["ms"], "valu_insts": v["valu_insts"], "issue_frac": v["valu_issue_frac"], "active_lanes": v["active_lanes"],
+                        "hbm_GBps": v["hbm_GBps"]}
+                    for k, v in pmc.get("per_kernel", {}).items() if v.get("valu_insts") or v.get("hbm_bytes")}
         out = {
             "metric": "Msamples/sec (=rays/sec) at 1080p Cornell+teapot, 256 spp; 1/2/4/8 GPU",
             "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic", "backend": (args.backend if world > 1 else None),
-            "config": {"workload": f"{args.config}: Cornell box (10 Triangle + 2 Sphere) + teapot StaticMesh (240 tris, reference-topology BVH)"
-                                   if cfgname == "cfg2" else "cfg1: Cornell box (10 Triangle + 2 Sphere)",
+            "config": {"workload": f"{args.config}: {CONFIGS[args.config]}",
                        "width": cam.screen_width, "height": cam.screen_height, "spp": cam.aa_sample_count,
                        "path_depth": cam.path_depth, "parallelism": f"tiles32x32_mod{world}",
                        "caller": "python ctypes over the C ABI (include/mi_rt.h)",
-                       "segments_per_sample": segs, "msegments_per_s": value * segs},
-            "roofline": {"bound": "hbm", "kernel": "K1w pipeline (wf_main + wf_trav per segment, wf_reduce)" if args.variant in (0, 7) else "pt_megakernel",
-                         "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel_ms": kernel_ms, "algorithmic_bytes_per_sample": b_sample,
-                         # per-kernel HIP events cost ~0.4 ms of barriers per frame: the library records them on
-                         # single-rank renders only (MI_RT_WF_KERNEL_TIMING=1 forces them)
+                       "segments_per_sample": segs, "msegments_per_s": (value * segs if segs else None),
+                       "multi_gpu_note": "N>1 numbers exist only where the driver ran this script on a multi-GPU node; "
+                                         "the builder's own N>1 figures are single-GPU rehearsals (DESIGN.md section 6)"},
+            "roofline": {"bound": "hbm",
+                         "kernel": "K1w pipeline pass (wf_main + wf_prefix + wf_trav per segment, wf_reduce)" if wavefront else "single-launch kernel",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": frac,
+                         "traffic": traffic, "traffic_source": traffic_source,
+                         "traffic_model_bytes": model_bytes, "path_counts": counts,
+                         "kernel_ms": kernel_ms,
                          "per_step_ms": ({"wf_main": per_step["wf_main_ms"], "wf_trav": per_step["wf_trav_ms"],
                                           "wf_reduce": per_step["wf_reduce_ms"], "launches": per_step["launches"]}
                                          if per_step["launches"] else None),
-                         "note": "algorithmic bytes = what traversal dereferences (SURVEY.md §8d): object list and BVH are "
-                                 "SGPR/LDS-resident; `traffic` = PMC-measured HBM bytes per pipeline pass, i.e. the path "
-                                 "state streamed between the phase kernels plus the framebuffer"},
+                         "valu": valu,
+                         "algorithmic_bytes_per_sample": b_sample,
+                         "note": "achieved = HBM bytes of one pipeline pass / its duration (HIP events on the launch stream). "
+                                 "The path state streamed between the phase kernels IS the traffic; the scene (object list, BVH) is "
+                                 "SGPR/LDS/L2-resident, so SURVEY 8(d)'s logical bytes are informational only. valu.issue_frac = "
+                                 "SQ_INSTS_VALU x 2 cycles / (1024 SIMDs x 2.4 GHz x kernel time)"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sc, flat)

@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libmi_rt.so")
 MI_TILE = 32
 
 # status codes (mi_status)
-MI_RT_ABI_VERSION = 2      # include/mi_rt.h
+MI_RT_ABI_VERSION = 3      # include/mi_rt.h
 MI_OK, MI_ERR_INVALID, MI_ERR_UNSUPPORTED, MI_ERR_NO_DEVICE, MI_ERR_HIP, MI_ERR_OOM, MI_ERR_NO_SCENE = 0, -1, -2, -3, -4, -5, -6
 # material kinds
 MI_MAT_LAMBERTIAN, MI_MAT_METAL, MI_MAT_DIELECTRIC, MI_MAT_PARAMETERIZED, MI_MAT_ISOTROPIC = range(5)
@@ -23,8 +23,9 @@ MI_MAT_LAMBERTIAN, MI_MAT_METAL, MI_MAT_DIELECTRIC, MI_MAT_PARAMETERIZED, MI_MAT
 MI_OBJ_SPHERE, MI_OBJ_TRIANGLE, MI_OBJ_PLANE, MI_OBJ_VOLUME, MI_OBJ_MESH = range(5)
 MI_PROJ_ORTHOGRAPHIC, MI_PROJ_PERSPECTIVE = 0, 1
 MI_SHADE_PHONG, MI_SHADE_PATHTRACE = 0, 1
-MI_VARIANT_DEFAULT, MI_VARIANT_SIMPLE, MI_VARIANT_PARKED, MI_VARIANT_VOTED, MI_VARIANT_VOTED_DIAG = 0, 1, 2, 3, 4
-MI_VARIANT_POOLED, MI_VARIANT_POOLED_DIAG, MI_VARIANT_WAVEFRONT, MI_VARIANT_RECURSIVE = 5, 6, 7, 8
+MI_VARIANT_DEFAULT, MI_VARIANT_SIMPLE, MI_VARIANT_VOTED, MI_VARIANT_VOTED_DIAG = 0, 1, 3, 4      # 2, 5, 6: removed in ABI 3
+MI_VARIANT_WAVEFRONT, MI_VARIANT_RECURSIVE = 7, 8
+MI_OPT_NO_TILE_MASKS, MI_OPT_REFERENCE_WALK, MI_OPT_TWO_STAGE = 1, 2, 4
 
 f3 = C.c_float * 3
 f16 = C.c_float * 16
@@ -92,7 +93,8 @@ class mi_camera_desc(C.Structure):
 
 class mi_render_opts(C.Structure):
     _fields_ = [("seed", C.c_uint32), ("rank", C.c_int32), ("world", C.c_int32),
-                ("variant", C.c_int32), ("want_signature", C.c_int32)]
+                ("variant", C.c_int32), ("want_signature", C.c_int32), ("flags", C.c_uint32),
+                ("max_state_bytes", C.c_uint64)]
 
 
 class mi_stats(C.Structure):
@@ -105,7 +107,7 @@ class mi_stats(C.Structure):
 EXPORTS = [
     "mi_ctx_create", "mi_ctx_destroy", "mi_scene_upload", "mi_render", "mi_compact_size",
     "mi_render_tiles_device", "mi_unpermute_device", "mi_tonemap_device", "mi_last_kernel_ms",
-    "mi_reserve", "mi_render_samples_device", "mi_last_pipeline_ms", "mi_last_diag", "mi_last_error", "mi_abi_version",
+    "mi_reserve", "mi_render_samples_device", "mi_last_pipeline_ms", "mi_last_pipeline_counts", "mi_last_diag", "mi_last_error", "mi_abi_version",
 ]
 
 _lib = None
@@ -159,10 +161,12 @@ def load() -> C.CDLL:
     lib.mi_tonemap_device.restype = C.c_int
     lib.mi_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     lib.mi_last_kernel_ms.restype = C.c_int
-    lib.mi_reserve.argtypes = [vp, C.POINTER(mi_camera_desc), C.c_int32]
+    lib.mi_reserve.argtypes = [vp, C.POINTER(mi_camera_desc), C.c_int32, C.c_uint64]
     lib.mi_reserve.restype = C.c_int
     lib.mi_last_pipeline_ms.argtypes = [vp, C.POINTER(C.c_float)]
     lib.mi_last_pipeline_ms.restype = C.c_int
+    lib.mi_last_pipeline_counts.argtypes = [vp, C.POINTER(C.c_uint64)]
+    lib.mi_last_pipeline_counts.restype = C.c_int
     lib.mi_last_diag.argtypes = [vp, C.POINTER(C.c_uint64)]
     lib.mi_last_diag.restype = C.c_int
     lib.mi_last_error.argtypes = []

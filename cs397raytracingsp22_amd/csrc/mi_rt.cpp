@@ -32,17 +32,13 @@
 #pragma clang fp contract(off)
 
 namespace pt {
-hipError_t launch_megakernel(const K1Args& args, uint32_t n_blocks, bool lds, bool park, bool sig,
-                             size_t lds_bytes, hipStream_t stream);
+hipError_t launch_megakernel(const K1Args& args, uint32_t n_blocks, bool lds, bool sig, size_t lds_bytes, hipStream_t stream);
 hipError_t launch_megakernel_voted(const K1Args& args, uint32_t n_blocks, bool lds, bool sig, bool diag,
                                    size_t lds_bytes, hipStream_t stream);
-hipError_t launch_megakernel_pooled(const K1Args& args, uint32_t tiles_padded, bool lds, bool sig, bool diag,
-                                    size_t lds_bytes, hipStream_t stream);
-size_t pooled_park_bytes(uint32_t tiles_padded);
 hipError_t launch_wf_main(const WfArgs& a, uint32_t n_blocks, bool sig, hipStream_t stream);
 hipError_t launch_phong(const K1Args& a, uint32_t n_blocks, bool sig, hipStream_t stream);
 hipError_t launch_branch(const K1Args& a, uint32_t n_blocks, uint32_t path_samples, bool sig, hipStream_t stream);
-hipError_t launch_wf_trav(const WfArgs& a, uint32_t n_blocks, int lds_mode, size_t lds_bytes, hipStream_t stream);
+hipError_t launch_wf_trav(const WfArgs& a, uint32_t n_blocks, int lds_mode, size_t lds_bytes, bool* big_lds_enabled, hipStream_t stream);
 hipError_t launch_wf_prefix(uint32_t* out_count, uint32_t* trav_count, uint32_t* in_count, uint32_t* in_blkpfx,
                             uint32_t* trav_pfx, uint32_t* hdr, uint32_t* host_hdr, uint32_t seq, hipStream_t stream);
 hipError_t launch_wf_reduce(const WfArgs& a, bool first_batch, bool last_batch, hipStream_t stream);
@@ -104,9 +100,10 @@ struct mi_ctx {
     uint8_t* d_u8 = nullptr;    size_t u8_bytes = 0;
     uint32_t* d_sigc = nullptr; size_t sigc_bytes = 0;
     uint32_t* d_sigi = nullptr; size_t sigi_bytes = 0;
-    unsigned long long* d_diag = nullptr;    // 8 counters of the diagnostic variant
+    unsigned long long* d_diag = nullptr;    // 16 counters of the diagnostic variant
     float point_light_pos[3] = {0.0f, 1.0f, 5.0f}, ambient[3] = {0.1f, 0.1f, 0.1f};   // Scene fields read by Phong
-    void* d_park = nullptr; size_t park_bytes = 0;   // parked path records of the POOLED kernel
+    hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;     // mi_render's whole-call timer
+    bool big_lds_enabled = false;                    // wf_trav<2,1024>'s > 64 KB dynamic-LDS opt-in, set on THIS context's device
     // wavefront pipeline buffers
     void* d_wf_a = nullptr; size_t wf_a_bytes = 0;   // path state ping
     void* d_wf_b = nullptr; size_t wf_b_bytes = 0;   // path state pong
@@ -114,7 +111,8 @@ struct mi_ctx {
     void* d_wf_samp = nullptr; size_t wf_samp_bytes = 0;
     void* d_wf_acc = nullptr; size_t wf_acc_bytes = 0;
     uint32_t* d_wf_cnt = nullptr;
-    uint32_t* h_hdr = nullptr;                       // pinned + device-mapped, 4 words: wf_prefix writes {blocks, live, queue, seq}
+    uint32_t* h_hdr = nullptr;                       // pinned + device-mapped, 8 words: wf_prefix writes {blocks, live, queue, seq, live class B}
+    uint64_t wf_counts[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };   // last frame: passes, class-A paths streamed, class-B paths, queue entries, samples, pixels
     uint32_t* h_hdr_dev = nullptr;                   // its device-side address
     uint32_t hdr_seq = 0;
     // per-tile primary-ray masks over the kind-grouped list (see tile_masks)
@@ -123,12 +121,23 @@ struct mi_ctx {
     std::vector<MeshBox> h_mesh_box;                 // world-space corners of every live mesh's root box
     std::vector<unsigned long long> h_tile_mask; void* d_tile_mask = nullptr; size_t tile_mask_bytes = 0;
     mi_camera_desc mask_cam{}; bool mask_valid = false;
-    uint64_t wf_max_paths = 0;                       // paths per batch; 0 = size from free HBM (MI_RT_WF_PATHS overrides)
     std::vector<hipEvent_t> wf_ev;                   // event pool for per-kernel timing of the pipeline
     float wf_ms[4] = { 0, 0, 0, 0 };                 // last frame: wf_main, wf_trav, wf_reduce totals (ms), launches
     int n_cus = 256;
-    uint32_t vote_t = 2, vote_a = 1, k_steps = 8;
-    uint32_t lds_pad = 0;
+    // Developer knobs (MI_RT_* environment variables), read ONCE in mi_ctx_create; none is needed for
+    // normal operation and none changes a result — what a caller may want to control is in mi_render_opts.
+    struct Tuning {
+        uint32_t vote_t = 2, vote_a = 1, k_steps = 8;   // voted megakernel
+        uint32_t lds_pad = 0;                           // occupancy experiments
+        uint32_t refill_min = 32;                       // wf_trav: refill idle lanes when at least this many are idle
+        int trav_lds = -1;                              // wf_trav LDS mode override (-1 = automatic)
+        int trav_bpc = 0;                               // wf_trav blocks per CU override (0 = automatic)
+        int kernel_timing = -1;                         // per-launch HIP events: -1 = single-rank renders only
+        bool global_bvh = false;                        // never stage a BVH in LDS
+        bool wf_stamps = false;                         // -DPT_WF_STAMPS builds: collect wf_main phase stamps
+        bool debug_mask = false;                        // print tile-mask statistics
+        uint32_t spin_timeout_ms = 120000;              // header wait: give up after this long without progress
+    } tune;
 };
 
 static int ensure(void** p, size_t* have, size_t want) {
@@ -142,6 +151,39 @@ static int ensure(void** p, size_t* have, size_t want) {
 
 extern "C" int mi_abi_version(void) { return MI_RT_ABI_VERSION; }
 extern "C" const char* mi_last_error(void) { return g_err.c_str(); }
+
+extern "C" void mi_ctx_destroy(mi_ctx* c);
+
+static int ctx_init(mi_ctx* c, const hipDeviceProp_t& prop) {
+    HIP_TRY(hipStreamCreate(&c->stream));
+    HIP_TRY(hipEventCreate(&c->ev_start));
+    HIP_TRY(hipEventCreate(&c->ev_stop));
+    HIP_TRY(hipEventCreate(&c->ev_t0));
+    HIP_TRY(hipEventCreate(&c->ev_t1));
+    HIP_TRY(hipMalloc((void**)&c->d_diag, 16 * sizeof(unsigned long long)));
+    c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    HIP_TRY(hipMalloc((void**)&c->d_wf_cnt, (9 * 256 + 64) * sizeof(uint32_t)));
+    HIP_TRY(hipHostMalloc((void**)&c->h_hdr, 8 * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent));
+    memset(c->h_hdr, 0, 8 * sizeof(uint32_t));
+    HIP_TRY(hipHostGetDevicePointer((void**)&c->h_hdr_dev, c->h_hdr, 0));
+    // developer knobs: read here, once (never on the render path)
+    mi_ctx::Tuning& t = c->tune;
+    auto env_u = [](const char* name, uint32_t& v) { if (const char* e = getenv(name)) v = (uint32_t)atoi(e); };
+    auto env_i = [](const char* name, int& v) { if (const char* e = getenv(name)) v = atoi(e); };
+    env_u("MI_RT_VOTE_T", t.vote_t); env_u("MI_RT_VOTE_A", t.vote_a); env_u("MI_RT_KSTEPS", t.k_steps);
+    if (const char* e = getenv("MI_RT_LDS_PAD_KB")) t.lds_pad = (uint32_t)atoi(e) * 1024u;
+    env_u("MI_RT_WF_REFILL", t.refill_min);
+    env_i("MI_RT_WF_TRAV_LDS", t.trav_lds); env_i("MI_RT_WF_TRAV_BPC", t.trav_bpc); env_i("MI_RT_WF_KERNEL_TIMING", t.kernel_timing);
+    t.global_bvh = getenv("MI_RT_GLOBAL_BVH") != nullptr;
+    t.wf_stamps = getenv("MI_RT_WF_STAMPS") != nullptr;
+    t.debug_mask = getenv("MI_RT_DEBUG_MASK") != nullptr;
+    env_u("MI_RT_SPIN_TIMEOUT_MS", t.spin_timeout_ms);
+    if (t.vote_t < 1) t.vote_t = 1;
+    if (t.k_steps < 1) t.k_steps = 1;
+    if (t.refill_min < 1) t.refill_min = 1;
+    if (t.refill_min > 64) t.refill_min = 64;
+    return MI_OK;
+}
 
 extern "C" int mi_ctx_create(int device, mi_ctx** out) {
     if (!out) return fail(MI_ERR_INVALID, "mi_ctx_create: out is NULL");
@@ -159,23 +201,13 @@ extern "C" int mi_ctx_create(int device, mi_ctx** out) {
         return fail(MI_ERR_NO_DEVICE, "device %d is %s; this library carries gfx950 (MI355X) code only", device, prop.gcnArchName);
     mi_ctx* c = new mi_ctx();
     c->device = device;
-    HIP_TRY(hipStreamCreate(&c->stream));
-    HIP_TRY(hipEventCreate(&c->ev_start));
-    HIP_TRY(hipEventCreate(&c->ev_stop));
-    HIP_TRY(hipMalloc((void**)&c->d_diag, 16 * sizeof(unsigned long long)));
-    // developer knobs of the voted kernel (defaults are the tuned values)
-    if (const char* e = getenv("MI_RT_VOTE_T")) c->vote_t = (uint32_t)atoi(e);
-    if (const char* e = getenv("MI_RT_VOTE_A")) c->vote_a = (uint32_t)atoi(e);
-    if (const char* e = getenv("MI_RT_KSTEPS")) c->k_steps = (uint32_t)atoi(e);
-    if (const char* e = getenv("MI_RT_WF_PATHS")) c->wf_max_paths = (uint64_t)atoll(e);
-    c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    HIP_TRY(hipMalloc((void**)&c->d_wf_cnt, (9 * 256 + 64) * sizeof(uint32_t)));
-    HIP_TRY(hipHostMalloc((void**)&c->h_hdr, 4 * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent));
-    memset(c->h_hdr, 0, 4 * sizeof(uint32_t));
-    HIP_TRY(hipHostGetDevicePointer((void**)&c->h_hdr_dev, c->h_hdr, 0));
-    if (const char* e = getenv("MI_RT_LDS_PAD_KB")) c->lds_pad = (uint32_t)atoi(e) * 1024u;   // occupancy experiments
-    if (c->vote_t < 1) c->vote_t = 1;
-    if (c->k_steps < 1) c->k_steps = 1;
+    const int rc = ctx_init(c, prop);
+    if (rc != MI_OK) {                 // release whatever was created (the message of the failure is kept)
+        const std::string msg = g_err;
+        mi_ctx_destroy(c);
+        g_err = msg;
+        return rc;
+    }
     *out = c;
     return MI_OK;
 }
@@ -191,7 +223,6 @@ extern "C" void mi_ctx_destroy(mi_ctx* c) {
     if (c->d_sigc) (void)hipFree(c->d_sigc);
     if (c->d_sigi) (void)hipFree(c->d_sigi);
     if (c->d_diag) (void)hipFree(c->d_diag);
-    if (c->d_park) (void)hipFree(c->d_park);
     if (c->d_wf_a) (void)hipFree(c->d_wf_a);
     if (c->d_wf_b) (void)hipFree(c->d_wf_b);
     if (c->d_wf_q) (void)hipFree(c->d_wf_q);
@@ -203,6 +234,8 @@ extern "C" void mi_ctx_destroy(mi_ctx* c) {
     for (hipEvent_t e : c->wf_ev) (void)hipEventDestroy(e);
     if (c->ev_start) (void)hipEventDestroy(c->ev_start);
     if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
+    if (c->ev_t0) (void)hipEventDestroy(c->ev_t0);
+    if (c->ev_t1) (void)hipEventDestroy(c->ev_t1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -298,8 +331,13 @@ extern "C" int mi_scene_upload(mi_ctx* c, const mi_scene_desc* d) {
         while (texels.size() % 16) texels.push_back(0);
         texs[(size_t)i].offset = (uint32_t)texels.size();
         texs[(size_t)i].width = t.width; texs[(size_t)i].height = t.height; texs[(size_t)i].pad = 0;
-        size_t nb = (size_t)t.width * t.height * 3;
-        texels.insert(texels.end(), t.rgb, t.rgb + nb);
+        // texels are padded to RGBA8 on the device: one aligned 4-byte load per fetch instead of three byte loads
+        const size_t np = (size_t)t.width * t.height, at = texels.size();
+        texels.resize(at + np * 4);
+        for (size_t k = 0; k < np; k++) {
+            texels[at + 4 * k] = t.rgb[3 * k]; texels[at + 4 * k + 1] = t.rgb[3 * k + 1]; texels[at + 4 * k + 2] = t.rgb[3 * k + 2];
+            texels[at + 4 * k + 3] = 255;
+        }
     }
 
     // meshes: BVH + de-indexed triangle pools
@@ -518,6 +556,7 @@ static int check_camera(const mi_camera_desc* cam) {
         return fail(MI_ERR_INVALID, "bad image size %ux%u", cam->screen_width, cam->screen_height);
     if (cam->aa_sample_count == 0) return fail(MI_ERR_INVALID, "aa_sample_count must be >= 1");
     if ((uint32_t)sqrtf((float)cam->aa_sample_count) == 0) return fail(MI_ERR_INVALID, "aa_sample_count too small");
+    if (!(cam->gamma > 0.0f) || !std::isfinite(cam->gamma)) return fail(MI_ERR_INVALID, "gamma must be finite and > 0 (tracing.rs:254 raises to 1/gamma)");
     return MI_OK;
 }
 
@@ -574,9 +613,10 @@ static void make_camera(const mi_camera_desc* cam, DCamera* C) {
 // frame, 531 M paths = 112 GB, is ONE batch), halved on allocation failure.
 static const size_t kWfBytesPerPath = 2 * (size_t)kWfPlanes * sizeof(float4) + 4 + sizeof(float4);
 
-static int wf_alloc(mi_ctx* c, WfArgs& a, uint32_t spp, uint32_t& s_batch) {
-    uint64_t max_paths = c->wf_max_paths;
-    if (max_paths == 0) {
+static int wf_alloc(mi_ctx* c, WfArgs& a, uint32_t spp, uint64_t max_state_bytes, uint32_t& s_batch) {
+    uint64_t max_paths;
+    if (max_state_bytes != 0) max_paths = max_state_bytes / kWfBytesPerPath;        // the caller's budget (mi_render_opts)
+    else {
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)8 << 30;
         // what this context already holds for the pipeline can be reused
@@ -609,13 +649,13 @@ static int wf_alloc(mi_ctx* c, WfArgs& a, uint32_t spp, uint32_t& s_batch) {
 }
 
 // sizes and allocates (host-side work: must happen BEFORE the timing start event is recorded)
-static int wf_prepare(mi_ctx* c, const mi_camera_desc* cam, uint32_t padded, WfArgs& a, uint32_t& s_batch) {
+static int wf_prepare(mi_ctx* c, const mi_camera_desc* cam, uint32_t padded, uint64_t max_state_bytes, WfArgs& a, uint32_t& s_batch) {
     memset(&a, 0, sizeof a);
     a.npix = padded * (uint32_t)kTilePixels;
     const uint32_t spp = cam->aa_sample_count;
     if (spp > 0xffffu) return fail(MI_ERR_UNSUPPORTED, "wavefront variant: aa_sample_count must be <= 65535");
     if (cam->path_depth > 0xffffu) return fail(MI_ERR_UNSUPPORTED, "wavefront variant: path_depth must be <= 65535");
-    return wf_alloc(c, a, spp, s_batch);
+    return wf_alloc(c, a, spp, max_state_bytes, s_batch);
 }
 
 // Primary-ray culling for the wavefront pipeline.  For every 32x32 tile: which Triangle / Sphere entries of
@@ -628,12 +668,12 @@ static int wf_prepare(mi_ctx* c, const mi_camera_desc* cam, uint32_t padded, WfA
 // dropped from the tile's mask and its test — which would have missed — is not run.  f64 on the host,
 // a further 1e-4 scene-unit slack; any non-finite value or a singular camera basis keeps everything.
 // Planes and ConvexVolumes are never masked.  Returns false when masking does not apply.
-static bool tile_masks(mi_ctx* c, const mi_camera_desc* cam) {
+static bool tile_masks(mi_ctx* c, const mi_camera_desc* cam, uint32_t flags) {
     const int n_ts = c->h_n_tri + c->h_n_sphere;
     const int n_mesh = (int)c->h_mesh_box.size();
     if ((n_ts == 0 && n_mesh == 0) || n_ts > 64 || n_mesh > 32) return false;
     // rays must leave the eye itself (no lens) towards the image plane (focus_dist > 0 keeps the direction's sign)
-    if (cam->projection_mode != MI_PROJ_PERSPECTIVE || cam->lens_radius != 0.0f || !(cam->focus_dist > 0.0f) || getenv("MI_RT_NO_TILE_MASK")) return false;
+    if (cam->projection_mode != MI_PROJ_PERSPECTIVE || cam->lens_radius != 0.0f || !(cam->focus_dist > 0.0f) || (flags & MI_OPT_NO_TILE_MASKS)) return false;
     if (c->mask_valid && memcmp(&c->mask_cam, cam, sizeof *cam) == 0) return true;
     const double W = cam->screen_width, H = cam->screen_height, p = 1.0 / H;
     const double view[3] = { cam->view_dir[0], cam->view_dir[1], cam->view_dir[2] };
@@ -772,7 +812,7 @@ static bool tile_masks(mi_ctx* c, const mi_camera_desc* cam) {
         c->h_tile_mask[n_tiles + (size_t)j * tx + i] = mm;
     }
     c->mask_cam = *cam; c->mask_valid = false;              // valid once uploaded
-    if (getenv("MI_RT_DEBUG_MASK")) {
+    if (c->tune.debug_mask) {
         size_t bits = 0, mbits = 0, dead = 0;
         for (size_t t = 0; t < n_tiles; t++) {
             bits += (size_t)__builtin_popcountll(c->h_tile_mask[t] & ((n_ts >= 64) ? ~0ull : ((1ull << n_ts) - 1ull)));
@@ -789,7 +829,7 @@ static bool tile_masks(mi_ctx* c, const mi_camera_desc* cam) {
 // begin == 0 starts the sums from zero; end == aa_sample_count also writes the per-pixel means.
 struct SampleRange { uint32_t begin, end; float4* accum; };
 
-static int render_tiles_wavefront(mi_ctx* c, const K1Args& k, const mi_camera_desc* cam, WfArgs a, uint32_t s_batch, bool lds,
+static int render_tiles_wavefront(mi_ctx* c, const K1Args& k, const mi_camera_desc* cam, WfArgs a, uint32_t s_batch, bool lds, uint32_t flags,
                                   float* d_compact, uint32_t* d_sig, SampleRange range, hipStream_t stream) {
     a.S = k.S; a.C = k.C; a.R = k.R; a.seed_key = k.seed_key;
     const uint32_t spp = cam->aa_sample_count;
@@ -810,7 +850,7 @@ static int render_tiles_wavefront(mi_ctx* c, const K1Args& k, const mi_camera_de
     a.trav_q = (uint32_t*)c->d_wf_q; a.samp = (float4*)c->d_wf_samp; a.accum = range.accum ? range.accum : (float4*)c->d_wf_acc;
     a.out = d_compact; a.sig = d_sig;
     a.tile_mask = nullptr;
-    if (tile_masks(c, cam)) {
+    if (tile_masks(c, cam, flags)) {
         if (!c->mask_valid) {
             int rcm = ensure(&c->d_tile_mask, &c->tile_mask_bytes, c->h_tile_mask.size() * sizeof(unsigned long long));
             if (rcm != MI_OK) return rcm;
@@ -820,20 +860,17 @@ static int render_tiles_wavefront(mi_ctx* c, const K1Args& k, const mi_camera_de
         a.tile_mask = (const unsigned long long*)c->d_tile_mask;
     }
     a.diag = nullptr;           // developer builds (-DPT_WF_STAMPS): phase stamps of wf_main
-    if (getenv("MI_RT_WF_STAMPS")) { a.diag = c->d_diag; HIP_TRY(hipMemsetAsync(c->d_diag, 0, 16 * sizeof(unsigned long long), stream)); }
-    a.refill_min = 32;
-    if (const char* e = getenv("MI_RT_WF_REFILL")) a.refill_min = (uint32_t)atoi(e);
-    if (a.refill_min < 1) a.refill_min = 1;
-    if (a.refill_min > 64) a.refill_min = 64;
+    if (c->tune.wf_stamps) { a.diag = c->d_diag; HIP_TRY(hipMemsetAsync(c->d_diag, 0, 16 * sizeof(unsigned long long), stream)); }
+    a.refill_min = c->tune.refill_min;
     // wf_trav LDS mode: 2 = BVH nodes in LDS, triangles through L1 (default when the nodes fit 64 KB:
     // teapot 15 KB -> 8 blocks per CU; 122.6 ms vs 126.0 ms for mode 1 on cfg2 1080p/256), 1 = nodes +
     // triangles (what the megakernels stage), 0 = everything from global memory
     const size_t node_bytes = (size_t)c->S.n_nodes * 32;
     // 3 = nodes in LDS too, but they need most of a CU's 160 KB: ONE 1024-thread block per CU (16 waves)
     int trav_lds_mode = 0;
-    if (c->S.n_meshes > 0 && !getenv("MI_RT_GLOBAL_BVH")) trav_lds_mode = node_bytes <= 64u * 1024u ? 2 : (node_bytes <= 156u * 1024u ? 3 : 0);
-    if (const char* e = getenv("MI_RT_WF_TRAV_LDS")) {
-        int m = atoi(e);
+    if (c->S.n_meshes > 0 && !c->tune.global_bvh) trav_lds_mode = node_bytes <= 64u * 1024u ? 2 : (node_bytes <= 156u * 1024u ? 3 : 0);
+    if (c->tune.trav_lds >= 0) {
+        const int m = c->tune.trav_lds;
         if (m == 0 || (m == 1 && lds) || (m == 2 && node_bytes <= 64u * 1024u) || (m == 3 && node_bytes <= 156u * 1024u)) trav_lds_mode = m;
     }
     const size_t trav_lds_bytes = trav_lds_mode == 1 ? c->lds_bytes : (trav_lds_mode >= 2 ? node_bytes : 0);
@@ -843,7 +880,7 @@ static int render_tiles_wavefront(mi_ctx* c, const K1Args& k, const mi_camera_de
     uint32_t trav_bpc = 6;                  // resident blocks per CU: bounded by LDS (160 KB) and by 8 waves/SIMD
     if (trav_lds_mode == 2) { trav_bpc = (uint32_t)((160u * 1024u) / (node_bytes ? node_bytes : 1)); if (trav_bpc > 8) trav_bpc = 8; if (trav_bpc < 2) trav_bpc = 2; }
     if (trav_lds_mode == 3) trav_bpc = 1;
-    if (const char* e = getenv("MI_RT_WF_TRAV_BPC")) trav_bpc = (uint32_t)atoi(e);
+    if (c->tune.trav_bpc > 0) trav_bpc = (uint32_t)c->tune.trav_bpc;
     const uint32_t trav_blocks = (uint32_t)c->n_cus * trav_bpc;
 
     // per-kernel timing: one event pair per launch, summed after the frame
@@ -852,7 +889,7 @@ static int render_tiles_wavefront(mi_ctx* c, const K1Args& k, const mi_camera_de
     // one event pair per launch is ~0.4 ms per frame of extra barriers: nothing on a whole frame (109 ms), 3 %
     // of a 1/8 share, so multi-rank renders skip it unless asked (MI_RT_WF_KERNEL_TIMING=0/1 overrides)
     bool per_kernel_timing = a.R.world == 1;
-    if (const char* e = getenv("MI_RT_WF_KERNEL_TIMING")) per_kernel_timing = atoi(e) != 0;
+    if (c->tune.kernel_timing >= 0) per_kernel_timing = c->tune.kernel_timing != 0;
     auto stamp = [&](int kind) -> int {      // kind: 0 wf_main, 1 wf_trav, 2 wf_reduce; call before AND after the launch
         if (!per_kernel_timing) return MI_OK;
         if (ev_used == c->wf_ev.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return MI_ERR_HIP; c->wf_ev.push_back(e); }
@@ -862,6 +899,8 @@ static int render_tiles_wavefront(mi_ctx* c, const K1Args& k, const mi_camera_de
     };
 #define WF_TIMED(kind, call) do { if (stamp(kind) != MI_OK) return fail(MI_ERR_HIP, "event"); HIP_TRY(call); if (stamp(kind) != MI_OK) return fail(MI_ERR_HIP, "event"); } while (0)
 
+    uint64_t counts[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    counts[4] = (uint64_t)a.npix * (range.end - range.begin); counts[5] = a.npix;
     for (uint32_t s0 = range.begin; s0 < range.end; s0 += s_batch) {
         a.s_base = s0; a.s_count = (s0 + s_batch <= range.end) ? s_batch : (range.end - s0);
         int cur = 0;
@@ -880,21 +919,27 @@ static int render_tiles_wavefront(mi_ctx* c, const K1Args& k, const mi_camera_de
             const uint32_t seq = ++c->hdr_seq;
             HIP_TRY(launch_wf_prefix(cnt, cnt + 2 * S_, d_in_count, d_in_pfx, d_trav_pfx, d_hdr, c->h_hdr_dev, seq, stream));
             if (c->S.n_meshes > 0)       // persistent walkers; they leave at once when the queue is empty
-                WF_TIMED(1, launch_wf_trav(a, trav_blocks, trav_lds_mode, trav_lds_bytes, stream));
+                WF_TIMED(1, launch_wf_trav(a, trav_blocks, trav_lds_mode, trav_lds_bytes, &c->big_lds_enabled, stream));
             // wait for wf_prefix's header (written into pinned host memory) while wf_trav runs
             {
                 volatile uint32_t* hh = c->h_hdr;
+                const auto t_wait = std::chrono::steady_clock::now();
                 for (uint32_t spin = 1; hh[3] != seq; spin++) {
                     if ((spin & 63u) == 0) {
                         hipError_t q = hipStreamQuery(stream);
                         if (q == hipSuccess) { if (hh[3] == seq) break; return fail(MI_ERR_HIP, "wavefront pipeline: stream drained without a header"); }
                         if (q != hipErrorNotReady) return fail(MI_ERR_HIP, "wavefront pipeline: %s", hipGetErrorString(q));
+                        // a wedged stream neither drains nor errors: bound the wait by wall clock (one pass is milliseconds)
+                        const auto waited = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t_wait).count();
+                        if (waited > (long long)c->tune.spin_timeout_ms)
+                            return fail(MI_ERR_HIP, "wavefront pipeline: no header from the device after %lld ms (stream wedged?)", (long long)waited);
                     }
                     std::this_thread::sleep_for(std::chrono::microseconds(20));
                 }
                 __atomic_thread_fence(__ATOMIC_ACQUIRE);
             }
             const uint32_t blk = c->h_hdr[0], n_live = c->h_hdr[1];
+            counts[0] += 1; counts[1] += n_live - c->h_hdr[4]; counts[2] += c->h_hdr[4]; counts[3] += c->h_hdr[2];
             if (n_live == 0) break;
             n_blocks = blk;
             cur ^= 1;
@@ -904,6 +949,7 @@ static int render_tiles_wavefront(mi_ctx* c, const K1Args& k, const mi_camera_de
     }
 #undef WF_TIMED
     HIP_TRY(hipStreamSynchronize(stream));
+    for (int k = 0; k < 8; k++) c->wf_counts[k] = counts[k];
     c->wf_ms[0] = c->wf_ms[1] = c->wf_ms[2] = 0.0f; c->wf_ms[3] = (float)(ev_used / 2);
     for (size_t e = 0; e + 1 < ev_used; e += 2) {
         float ms = 0.0f;
@@ -942,24 +988,18 @@ static int render_tiles(mi_ctx* c, const mi_camera_desc* cam, const mi_render_op
     a.R.seed = o->seed; a.R.rank = o->rank; a.R.world = o->world;
     a.R.tiles_x = tx; a.R.tiles_y = ty; a.R.tiles_total = total;
     a.R.my_tiles = (total > (uint32_t)o->rank) ? (total - (uint32_t)o->rank + (uint32_t)o->world - 1) / (uint32_t)o->world : 0;
-    bool lds = c->S.n_meshes > 0 && c->lds_bytes <= 64u * 1024u && !getenv("MI_RT_GLOBAL_BVH");   // env: developer experiment
+    bool lds = c->S.n_meshes > 0 && c->lds_bytes <= 64u * 1024u && !c->tune.global_bvh;
     a.R.lds_nodes = lds ? (uint32_t)c->S.n_nodes : 0;
     a.R.lds_tris = lds ? (uint32_t)c->S.n_tris : 0;
     a.seed_key = lowbias32(o->seed ^ 0x68e31da4u);
     a.out = d_compact;
     a.sig = (o->want_signature && d_sig) ? d_sig : nullptr;
     int variant = o->variant == MI_VARIANT_DEFAULT ? MI_VARIANT_WAVEFRONT : o->variant;
-    if (variant < MI_VARIANT_SIMPLE || variant > MI_VARIANT_RECURSIVE) return fail(MI_ERR_INVALID, "unknown variant %d", o->variant);
-    const bool pooled = variant == MI_VARIANT_POOLED || variant == MI_VARIANT_POOLED_DIAG;
-    const bool diag = variant == MI_VARIANT_VOTED_DIAG || variant == MI_VARIANT_POOLED_DIAG;
-    a.park = nullptr;
-    if (pooled) {
-        int rc2 = ensure(&c->d_park, &c->park_bytes, pooled_park_bytes(padded));
-        if (rc2 != MI_OK) return rc2;
-        a.park = (float4*)c->d_park;
-    }
-    bool park = variant == MI_VARIANT_PARKED && c->S.n_meshes > 0;
-    a.R.vote_t = c->vote_t; a.R.vote_a = c->vote_a; a.R.k_steps = c->k_steps;
+    if (variant != MI_VARIANT_SIMPLE && variant != MI_VARIANT_VOTED && variant != MI_VARIANT_VOTED_DIAG &&
+        variant != MI_VARIANT_WAVEFRONT && variant != MI_VARIANT_RECURSIVE)
+        return fail(MI_ERR_INVALID, "unknown variant %d (2, 5 and 6 were removed in ABI 3)", o->variant);
+    const bool diag = variant == MI_VARIANT_VOTED_DIAG;
+    a.R.vote_t = c->tune.vote_t; a.R.vote_a = c->tune.vote_a; a.R.k_steps = c->tune.k_steps;
     a.diag = nullptr;
     uint32_t n_blocks = padded * (uint32_t)kBlocksPerTile;
     if (diag) {
@@ -968,7 +1008,7 @@ static int render_tiles(mi_ctx* c, const mi_camera_desc* cam, const mi_render_op
     }
     WfArgs wa; uint32_t wf_batch = 1;
     if (variant == MI_VARIANT_WAVEFRONT && !phong && !recursive) {
-        int rcp = wf_prepare(c, cam, padded, wa, wf_batch);
+        int rcp = wf_prepare(c, cam, padded, o->max_state_bytes, wa, wf_batch);
         if (rcp != MI_OK) return rcp;
     }
     HIP_TRY(hipEventRecord(c->ev_start, stream));
@@ -977,14 +1017,12 @@ static int render_tiles(mi_ctx* c, const mi_camera_desc* cam, const mi_render_op
     else if (recursive)
         HIP_TRY(launch_branch(a, n_blocks, cam->path_samples, a.sig != nullptr, stream));
     else if (variant == MI_VARIANT_WAVEFRONT) {
-        int rcw = render_tiles_wavefront(c, a, cam, wa, wf_batch, lds, d_compact, a.sig, range, stream);
+        int rcw = render_tiles_wavefront(c, a, cam, wa, wf_batch, lds, o->flags, d_compact, a.sig, range, stream);
         if (rcw != MI_OK) return rcw;
-    } else if (pooled)
-        HIP_TRY(launch_megakernel_pooled(a, padded, lds, a.sig != nullptr, diag, c->lds_bytes, stream));
-    else if (variant == MI_VARIANT_VOTED || variant == MI_VARIANT_VOTED_DIAG)
-        HIP_TRY(launch_megakernel_voted(a, n_blocks, lds, a.sig != nullptr, diag, c->lds_bytes + c->lds_pad, stream));
+    } else if (variant == MI_VARIANT_VOTED || variant == MI_VARIANT_VOTED_DIAG)
+        HIP_TRY(launch_megakernel_voted(a, n_blocks, lds, a.sig != nullptr, diag, c->lds_bytes + c->tune.lds_pad, stream));
     else
-        HIP_TRY(launch_megakernel(a, n_blocks, lds, park, a.sig != nullptr, c->lds_bytes, stream));
+        HIP_TRY(launch_megakernel(a, n_blocks, lds, a.sig != nullptr, c->lds_bytes, stream));
     HIP_TRY(hipEventRecord(c->ev_stop, stream));
     c->ev_recorded = true;
     if (st) {
@@ -1048,7 +1086,7 @@ extern "C" int mi_last_kernel_ms(mi_ctx* c, float* ms) {
     return MI_OK;
 }
 
-extern "C" int mi_reserve(mi_ctx* c, const mi_camera_desc* cam, int32_t world) {
+extern "C" int mi_reserve(mi_ctx* c, const mi_camera_desc* cam, int32_t world, uint64_t max_state_bytes) {
     if (!c) return fail(MI_ERR_INVALID, "ctx is NULL");
     int rc = check_camera(cam);
     if (rc != MI_OK) return rc;
@@ -1060,12 +1098,18 @@ extern "C" int mi_reserve(mi_ctx* c, const mi_camera_desc* cam, int32_t world) {
     memset(&a, 0, sizeof a);
     a.npix = padded * (uint32_t)kTilePixels;
     uint32_t s_batch = 1;
-    return wf_alloc(c, a, cam->aa_sample_count, s_batch);
+    return wf_alloc(c, a, cam->aa_sample_count, max_state_bytes, s_batch);
 }
 
 extern "C" int mi_last_pipeline_ms(mi_ctx* c, float* out4) {
     if (!c || !out4) return fail(MI_ERR_INVALID, "mi_last_pipeline_ms: bad argument");
     for (int i = 0; i < 4; i++) out4[i] = c->wf_ms[i];
+    return MI_OK;
+}
+
+extern "C" int mi_last_pipeline_counts(mi_ctx* c, uint64_t* out8) {
+    if (!c || !out8) return fail(MI_ERR_INVALID, "mi_last_pipeline_counts: bad argument");
+    for (int i = 0; i < 8; i++) out8[i] = c->wf_counts[i];
     return MI_OK;
 }
 
@@ -1085,8 +1129,7 @@ extern "C" int mi_render(mi_ctx* c, const mi_camera_desc* cam, const mi_render_o
     int rc = check_camera(cam);
     if (rc != MI_OK) return rc;
     HIP_TRY(hipSetDevice(c->device));
-    hipEvent_t t0, t1;
-    HIP_TRY(hipEventCreate(&t0)); HIP_TRY(hipEventCreate(&t1));
+    const hipEvent_t t0 = c->ev_t0, t1 = c->ev_t1;      // owned by the context: no early return can leak them
     uint32_t tx, ty, total, padded;
     tile_counts(cam, 1, &tx, &ty, &total, &padded);
     size_t npix = (size_t)cam->screen_width * cam->screen_height;
@@ -1121,6 +1164,5 @@ extern "C" int mi_render(mi_ctx* c, const mi_camera_desc* cam, const mi_render_o
         HIP_TRY(hipEventElapsedTime(&ms, c->ev_start, c->ev_stop)); stats->kernel_ms = ms;
         HIP_TRY(hipEventElapsedTime(&ms, t0, t1)); stats->total_ms = ms;
     }
-    (void)hipEventDestroy(t0); (void)hipEventDestroy(t1);
     return MI_OK;
 }

@@ -169,8 +169,7 @@ struct K1Args {
     uint32_t seed_key;   // lowbias32(seed ^ 0x68e31da4)
     float*    out;       // [tiles_padded][1024][3]
     uint32_t* sig;       // [tiles_padded][1024] or nullptr
-    unsigned long long* diag;   // 8 counters (diagnostic build only) or nullptr
-    float4* park;               // POOLED kernel: parked path records [block][v][q][thread]
+    unsigned long long* diag;   // 16 counters (diagnostic build only) or nullptr
 };
 
 // ---- wavefront pipeline (pt_kernels.hip "K1w") ----

@@ -22,8 +22,8 @@
 //     staged into LDS when they fit (teapot: 479 nodes + 240 triangles = 26.8 KB).
 //   * VOTED variant (default, pt_megakernel_voted): each lane is a state machine and every
 //     trip of the wave-wide loop votes with __ballot/__popcll which phase runs — the BVH node
-//     step, not the segment, is the scheduling unit.  SIMPLE / PARKED (pt_megakernel) and
-//     POOLED are kept as structural cross-checks and recorded experiments.
+//     step, not the segment, is the scheduling unit.  SIMPLE (pt_megakernel) is kept as a
+//     structural cross-check.
 //
 // Numerics: every expression is written in the reference's evaluation order; the file
 // is compiled with -ffp-contract=off (Rust never fuses a*b+c) and HIP's default
@@ -321,8 +321,9 @@ __device__ __forceinline__ f3 tex_sample(const DScene& S, int tex, float u, floa
     if (x > W - 1u) x = W - 1u;
     uint32_t y = (uint32_t)((1.0f - clampf(v, 0.0f, 0.999f)) * (float)H);
     if (y > H - 1u) y = H - 1u;
-    auto px = S.texels + t_offset + ((size_t)y * W + x) * 3;
-    return mk3((float)px[0] / 255.0f, (float)px[1] / 255.0f, (float)px[2] / 255.0f);
+    // texels are RGBA8 on the device (padded by the scene compiler): ONE aligned 4-byte load per fetch
+    const uint32_t px = ((const PT_CONST_AS uint32_t*)(S.texels + t_offset))[(size_t)y * W + x];
+    return mk3((float)(px & 0xffu) / 255.0f, (float)((px >> 8) & 0xffu) / 255.0f, (float)((px >> 16) & 0xffu) / 255.0f);
 }
 
 // ---------------------------------------------------------------- BVH storage access
@@ -715,7 +716,7 @@ __device__ __forceinline__ uint32_t sig_end_miss(uint32_t sig, const Rng& r) {
 __device__ __forceinline__ uint32_t sig_end_depth(uint32_t sig) { return lowbias32(sig ^ 0x5bd1e995u); }
 
 // ---------------------------------------------------------------- K1
-template <bool LDS, bool PARK, bool SIG>
+template <bool LDS, bool SIG>
 __global__ __launch_bounds__(kBlock) void pt_megakernel(K1Args A) {
     const DScene& S = A.S;
     const DCamera& C = A.C;
@@ -758,110 +759,63 @@ __global__ __launch_bounds__(kBlock) void pt_megakernel(K1Args A) {
     P.o = P.d = P.T = P.L = mk3(0.0f, 0.0f, 0.0f); P.depth = 0; P.sig = 0; P.rng.s0 = P.rng.s1 = 1u;
     bool fresh = true;          // lane needs a new camera ray
     bool alive = true;          // lane still has samples to do
-
-    // PARK state: the lane's ray entered >=1 mesh root box and waits for the traversal phase
-    bool parked = false;
     Best best; best.t = 0.0f; best.obj = -1; best.tri = -1; best.u = best.v = 0.0f;
 
-    while (true) {
-        bool run_list = true, run_mesh = true;
-        if (PARK) {
-            // phase vote: trace the mesh phase only when most lanes wait for it
-            unsigned long long m_park = __ballot(alive && parked);
-            unsigned long long m_list = __ballot(alive && !parked);
-            int n_park = __popcll(m_park), n_list = __popcll(m_list);
-            if (n_park == 0 && n_list == 0) break;
-            run_mesh = (n_list == 0) || (n_park >= 40);
-            run_list = !run_mesh;
+    while (__any(alive)) {
+        if (alive && fresh) {
+            if (sample >= spp) alive = false;
+            else {
+                rng_init(P.rng, A.seed_key, pixel, sample);
+                generate_ray(C, px, py, sample, P.rng, P.o, P.d);
+                P.T = mk3(1.0f, 1.0f, 1.0f); P.L = mk3(0.0f, 0.0f, 0.0f); P.depth = 0; P.sig = 0;
+                fresh = false;
+            }
+        }
+        if (alive) {
+        // ---- Scene::intersect_ray (tracing.rs:330-344): objects in order, wave-uniform index ----
+        best.obj = -1; best.t = 0.0f; best.tri = -1; best.u = best.v = 0.0f;
+        for (int k = 0; k < S.n_objects; k++) {
+            auto ob = &S.objects[k];
+            if (ob->kind != OBJ_MESH) test_object(ob, k, P.o, P.d, t_min, t_max, P.rng, best);
+        }
+        for (int m = 0; m < S.n_meshes; m++) {                            // StaticMesh::intersect_ray geometry.rs:301-314
+            auto M = &S.meshes[m];
+            f3 oo = xform_point(M->inv_transform, P.o);
+            f3 od = xform_vector(M->inv_transform, P.d);
+            float bt, bu, bv; int btri;
+            traverse_mesh(B, M->node_begin, M->node_end, M->tri_begin, oo, od, t_min, t_max, bt, btri, bu, bv);
+            if (btri >= 0) consider(best, bt, M->object_index, btri, bu, bv);
+        }
+        // ---- Scene::shade_ray, one level (tracing.rs:305-321) ----
+        bool end_path;
+        if (best.obj < 0) {                                           // :306 background = 0
+            end_path = true;
+            if (SIG) P.sig = sig_end_miss(P.sig, P.rng);
         } else {
-            if (!__any(alive)) break;
-        }
-
-        bool resolved = false;   // this lane finished a segment's intersection this trip
-
-        if (run_list && alive && !parked) {
-            if (fresh) {
-                if (sample >= spp) { alive = false; }
-                else {
-                    rng_init(P.rng, A.seed_key, pixel, sample);
-                    generate_ray(C, px, py, sample, P.rng, P.o, P.d);
-                    P.T = mk3(1.0f, 1.0f, 1.0f); P.L = mk3(0.0f, 0.0f, 0.0f); P.depth = 0; P.sig = 0;
-                    fresh = false;
-                }
-            }
-            if (alive) {
-                // ---- Scene::intersect_ray over the non-mesh objects, wave-uniform index ----
-                best.obj = -1; best.t = 0.0f; best.tri = -1; best.u = best.v = 0.0f;
-                for (int k = 0; k < S.n_objects; k++) {
-                    auto ob = &S.objects[k];
-                    if (ob->kind != OBJ_MESH) test_object(ob, k, P.o, P.d, t_min, t_max, P.rng, best);
-                }
-                if (S.n_meshes == 0) resolved = true;
-                else if (PARK) {
-                    // does the ray enter any mesh root box?  (geometry.rs:103 at the root)
-                    bool enters = false;
-                    for (int m = 0; m < S.n_meshes; m++) {
-                        auto M = &S.meshes[m];
-                        f3 oo = xform_point(M->inv_transform, P.o);
-                        f3 od = xform_vector(M->inv_transform, P.d);
-                        float4 n0, n1;
-                        B.node(M->node_begin, n0, n1);
-                        if (__float_as_int(n1.w) >= 0) enters = true;      // single-triangle mesh: root is a leaf
-                        else {
-                            f3 inv_d = mk3(1.0f / od.x, 1.0f / od.y, 1.0f / od.z);
-                            enters = enters || slab(mk3(n0.x, n0.y, n0.z), mk3(n1.x, n1.y, n1.z), oo, inv_d, t_min, t_max);
-                        }
-                    }
-                    if (enters) parked = true; else resolved = true;
-                }
-            }
-        }
-
-        if (run_mesh && alive && (PARK ? parked : (!resolved && S.n_meshes > 0))) {
-            // ---- StaticMesh::intersect_ray for every mesh (geometry.rs:301-314) ----
-            for (int m = 0; m < S.n_meshes; m++) {
-                auto M = &S.meshes[m];
-                f3 oo = xform_point(M->inv_transform, P.o);
-                f3 od = xform_vector(M->inv_transform, P.d);
-                float bt, bu, bv; int btri;
-                traverse_mesh(B, M->node_begin, M->node_end, M->tri_begin, oo, od, t_min, t_max, bt, btri, bu, bv);
-                if (btri >= 0) consider(best, bt, M->object_index, btri, bu, bv);
-            }
-            parked = false;
-            resolved = true;
-        }
-
-        if (resolved) {
-            // ---- Scene::shade_ray, one level (tracing.rs:305-321) ----
-            bool end_path;
-            if (best.obj < 0) {                                           // :306 background = 0
+            if (SIG) P.sig = sig_hit(P.sig, best.t, best.obj);
+            Surf s;
+            resolve_hit(S, best, P.o, P.d, s);
+            // L += T * emission                                         :321
+            P.L = mk3(P.L.x + P.T.x * s.emission.x, P.L.y + P.T.y * s.emission.y, P.L.z + P.T.z * s.emission.z);
+            P.depth++;
+            if (P.depth >= C.path_depth) {                            // :301 at the next level
                 end_path = true;
-                if (SIG) P.sig = sig_end_miss(P.sig, P.rng);
+                if (SIG) P.sig = sig_end_depth(P.sig);
             } else {
-                if (SIG) P.sig = sig_hit(P.sig, best.t, best.obj);
-                Surf s;
-                resolve_hit(S, best, P.o, P.d, s);
-                // L += T * emission                                         :321
-                P.L = mk3(P.L.x + P.T.x * s.emission.x, P.L.y + P.T.y * s.emission.y, P.L.z + P.T.z * s.emission.z);
-                P.depth++;
-                if (P.depth >= C.path_depth) {                            // :301 at the next level
-                    end_path = true;
-                    if (SIG) P.sig = sig_end_depth(P.sig);
-                } else {
-                    f3 nd, w;
-                    scatter(s, P.d, P.rng, nd, w);                        // :312-316
-                    P.o = s.p; P.d = nd;
-                    P.T = mk3(P.T.x * w.x, P.T.y * w.y, P.T.z * w.z);
-                    end_path = false;
-                }
-            }
-            if (end_path) {
-                accum = accum + P.L;                                      // :238
-                if (SIG) sigsum += P.sig;
-                sample++;
-                fresh = true;
+                f3 nd, w;
+                scatter(s, P.d, P.rng, nd, w);                        // :312-316
+                P.o = s.p; P.d = nd;
+                P.T = mk3(P.T.x * w.x, P.T.y * w.y, P.T.z * w.z);
+                end_path = false;
             }
         }
+        if (end_path) {
+            accum = accum + P.L;                                      // :238
+            if (SIG) sigsum += P.sig;
+            sample++;
+            fresh = true;
+        }
+        }   // alive
     }
 
     // ---- per-pixel mean (tracing.rs:241); pixels outside the image are written as 0 ----
@@ -1075,7 +1029,7 @@ __global__ __launch_bounds__(kBlock) void pt_branch(K1Args A, uint32_t path_samp
 // ---------------------------------------------------------------- K1, voted state machine
 // The divergent part of the path is the BVH walk: a ray that enters the teapot takes
 // 20..150 node steps, its 63 neighbours take 0.  Running the walk to completion inside
-// a segment (SIMPLE / PARKED above) makes the wave wait for its slowest lane.  Here the
+// a segment (SIMPLE above) makes the wave wait for its slowest lane.  Here the
 // scheduling unit is ONE NODE STEP.  Every lane is a small state machine:
 //     A     not inside a mesh: shade the pending hit, start a new sample if the path
 //           ended, walk the object list for the next segment, test the mesh root boxes
@@ -1315,248 +1269,6 @@ __global__ __launch_bounds__(kBlock, PT_MIN_WAVES) void pt_megakernel_voted(K1Ar
         atomicAdd(&A.diag[8], dg_cycA); atomicAdd(&A.diag[9], dg_cycB);
         atomicAdd(&A.diag[10], dg_cycShade); atomicAdd(&A.diag[11], dg_cycGen); atomicAdd(&A.diag[12], dg_cycList);
         atomicAdd(&A.diag[13], dg_slabs); atomicAdd(&A.diag[14], dg_roots);
-    }
-}
-
-// ---------------------------------------------------------------- K1, pooled (two path slots per lane)
-// The voted kernel's DIAG counters show the limit of one path per lane: lanes in A idle during
-// B trips and lanes in TRAV idle during A trips (A 50 %, interior 30 %, leaf 26 % active).
-// Here every lane owns kV = 2 PIXELS (two path slots): one slot is live in registers, the
-// other is PARKED in a per-lane record in global memory (44 dwords, L2-resident; a lane only
-// ever reads back what it stored itself, so no cross-lane ordering is involved).  A lane whose
-// live path is not in the voted phase swaps to its parked path when that one is, so an A trip
-// runs every lane that has ANY path in A, a B trip every lane with ANY path inside a BVH.
-// A workgroup covers a 32 x 16 half tile (slot v of a lane = rows v*8 .. v*8+7 of it); each
-// pixel is still traced sample by sample by one lane, so results are bit-identical.
-constexpr int kV = 2;
-constexpr int kParkQ = 11;                       // float4 per parked record
-
-struct Slot {            // the part of a path slot that is NOT in `Path`/`Best`
-    f3 accum; uint32_t sigsum, sample;
-    int state; bool fresh, pending;
-    int tm, ti, tend, ttb, tbtri;
-    f3 too, tod, tinv; float tbt, tbu, tbv;
-};
-
-template <bool LDS, bool SIG, bool DIAG>
-__global__ __launch_bounds__(kBlock, PT_MIN_WAVES) void pt_megakernel_pooled(K1Args A) {
-    const DScene& S = A.S;
-    const DCamera& C = A.C;
-
-    Bvh<LDS> B;
-    if (LDS) {
-        cf4_ptr gn = (cf4_ptr)S.nodes;
-        cf4_ptr gt = (cf4_ptr)S.tris;
-        int nn = (int)A.R.lds_nodes * 2, nt = (int)A.R.lds_tris * 3;
-        for (int k = threadIdx.x; k < nn; k += kBlock) k1_lds[k] = gn[k];
-        for (int k = threadIdx.x; k < nt; k += kBlock) k1_lds[nn + k] = gt[k];
-        __syncthreads();
-    }
-    bvh_bind(B, S, (int)A.R.lds_nodes * 2);
-
-    constexpr uint32_t kBlocksPerTileP = kTilePixels / (kBlock * kV);     // 2 half tiles
-    const uint32_t slot = blockIdx.x / kBlocksPerTileP;
-    const uint32_t sub = blockIdx.x % kBlocksPerTileP;
-    const uint32_t tile = slot * (uint32_t)A.R.world + (uint32_t)A.R.rank;
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t in_x = wave * 8 + (lane & 7);
-    const bool tile_ok = tile < A.R.tiles_total;
-    const uint32_t px = tile_ok ? (tile % A.R.tiles_x) * kTile + in_x : 0u;
-    const uint32_t tile_y0 = tile_ok ? (tile / A.R.tiles_x) * kTile : 0u;
-    const float t_min = 0.001f, t_max = C.max_trace_dist;
-    const int vote_t = (int)A.R.vote_t, vote_a = (int)A.R.vote_a, k_steps = (int)A.R.k_steps;
-
-    // this lane's park records: [block][v][q][thread] float4 (coalesced per q)
-    float4* park = A.park + ((size_t)blockIdx.x * kV * kParkQ) * kBlock + threadIdx.x;
-
-    enum : int { ST_A = 0, ST_TRAV = 1, ST_DEAD = 2 };
-
-    // per-slot pixel identity, recomputed whenever the live slot changes
-    int cur = 0;
-    uint32_t in_y, py, pixel, out_idx, spp;
-    auto bind_pixel = [&](int v) {
-        in_y = sub * (8 * kV) + (uint32_t)v * 8 + (lane >> 3);
-        py = tile_y0 + in_y;
-        pixel = py * C.width + px;
-        out_idx = slot * kTilePixels + in_y * kTile + in_x;
-        spp = (tile_ok && px < C.width && py < C.height) ? C.spp : 0u;
-    };
-    bind_pixel(0);
-
-    Path P;
-    P.o = P.d = P.T = P.L = mk3(0.0f, 0.0f, 0.0f); P.depth = 0; P.sig = 0; P.rng.s0 = P.rng.s1 = 1u;
-    Best best; best.t = 0.0f; best.obj = -1; best.tri = -1; best.u = best.v = 0.0f;
-    Slot Q;
-    Q.accum = mk3(0.0f, 0.0f, 0.0f); Q.sigsum = 0; Q.sample = 0; Q.state = ST_A; Q.fresh = true; Q.pending = false;
-    Q.tm = Q.ti = Q.tend = Q.ttb = 0; Q.tbtri = -1;
-    Q.too = Q.tod = Q.tinv = mk3(0.0f, 0.0f, 0.0f); Q.tbt = Q.tbu = Q.tbv = 0.0f;
-    int pstate = ST_A;                                   // state of the parked slot (kept in a register for the votes)
-
-    // the parked slot starts as an untouched pixel: all zero, flags = A | fresh
-    {
-        float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        float4* rec = park + (size_t)1 * kParkQ * kBlock;
-#pragma unroll
-        for (int q = 0; q < kParkQ - 1; q++) rec[(size_t)q * kBlock] = z;
-        rec[(size_t)(kParkQ - 1) * kBlock] = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(ST_A | 4));
-    }
-
-    unsigned long long dg_tripsA = 0, dg_lanesA = 0, dg_tripsI = 0, dg_lanesI = 0, dg_tripsL = 0, dg_lanesL = 0, dg_tripsB = 0;
-
-    while (true) {
-        const int nA = __popcll(__ballot(Q.state == ST_A || pstate == ST_A));
-        const int nT = __popcll(__ballot(Q.state == ST_TRAV || pstate == ST_TRAV));
-        if (nA + nT == 0) break;
-        const bool run_b = (nT > 0) && (nT * vote_t >= nA * vote_a);
-        const int want = run_b ? ST_TRAV : ST_A;
-
-        // ---- swap the live path with the parked one when only the parked one is in the voted phase ----
-        if (Q.state != want && pstate == want) {
-            float4* mine = park + (size_t)cur * kParkQ * kBlock;
-            float4* other = park + (size_t)(1 - cur) * kParkQ * kBlock;
-            float4 r0 = other[0 * kBlock], r1 = other[1 * kBlock], r2 = other[2 * kBlock], r3 = other[3 * kBlock];
-            float4 r4 = other[4 * kBlock], r5 = other[5 * kBlock], r6 = other[6 * kBlock], r7 = other[7 * kBlock];
-            float4 r8 = other[8 * kBlock], r9 = other[9 * kBlock], r10 = other[10 * kBlock];
-            if (Q.state != ST_DEAD) {
-                mine[0 * kBlock] = make_float4(P.o.x, P.o.y, P.o.z, P.d.x);
-                mine[1 * kBlock] = make_float4(P.d.y, P.d.z, P.T.x, P.T.y);
-                mine[2 * kBlock] = make_float4(P.T.z, P.L.x, P.L.y, P.L.z);
-                mine[3 * kBlock] = make_float4(Q.accum.x, Q.accum.y, Q.accum.z, __uint_as_float(P.rng.s0));
-                mine[4 * kBlock] = make_float4(__uint_as_float(P.rng.s1), __uint_as_float(Q.sample), __uint_as_float(P.depth), __uint_as_float(P.sig));
-                mine[5 * kBlock] = make_float4(__uint_as_float(Q.sigsum), best.t, __int_as_float(best.obj), __int_as_float(best.tri));
-                mine[6 * kBlock] = make_float4(best.u, best.v, Q.tbt, __int_as_float(Q.tbtri));
-                mine[7 * kBlock] = make_float4(Q.tbu, Q.tbv, __int_as_float(Q.ti), __int_as_float(Q.tm));
-                mine[8 * kBlock] = make_float4(Q.too.x, Q.too.y, Q.too.z, Q.tod.x);
-                mine[9 * kBlock] = make_float4(Q.tod.y, Q.tod.z, Q.tinv.x, Q.tinv.y);
-                mine[10 * kBlock] = make_float4(Q.tinv.z, __int_as_float(Q.tend), __int_as_float(Q.ttb),
-                                                __int_as_float(Q.state | (Q.fresh ? 4 : 0) | (Q.pending ? 8 : 0)));
-            }
-            const int old_state = Q.state;
-            P.o = mk3(r0.x, r0.y, r0.z); P.d = mk3(r0.w, r1.x, r1.y); P.T = mk3(r1.z, r1.w, r2.x); P.L = mk3(r2.y, r2.z, r2.w);
-            Q.accum = mk3(r3.x, r3.y, r3.z); P.rng.s0 = __float_as_uint(r3.w);
-            P.rng.s1 = __float_as_uint(r4.x); Q.sample = __float_as_uint(r4.y); P.depth = __float_as_uint(r4.z); P.sig = __float_as_uint(r4.w);
-            Q.sigsum = __float_as_uint(r5.x); best.t = r5.y; best.obj = __float_as_int(r5.z); best.tri = __float_as_int(r5.w);
-            best.u = r6.x; best.v = r6.y; Q.tbt = r6.z; Q.tbtri = __float_as_int(r6.w);
-            Q.tbu = r7.x; Q.tbv = r7.y; Q.ti = __float_as_int(r7.z); Q.tm = __float_as_int(r7.w);
-            Q.too = mk3(r8.x, r8.y, r8.z); Q.tod = mk3(r8.w, r9.x, r9.y); Q.tinv = mk3(r9.z, r9.w, r10.x);
-            Q.tend = __float_as_int(r10.y); Q.ttb = __float_as_int(r10.z);
-            const int fl = __float_as_int(r10.w);
-            Q.state = fl & 3; Q.fresh = (fl & 4) != 0; Q.pending = (fl & 8) != 0;
-            pstate = old_state;
-            cur = 1 - cur;
-            bind_pixel(cur);
-        }
-
-        if (!run_b) {
-            if (DIAG) { dg_tripsA++; dg_lanesA += (unsigned long long)__popcll(__ballot(Q.state == ST_A)); }
-            if (Q.state == ST_A) {
-                // ---- (a) Scene::shade_ray, one level, for the intersection found earlier ----
-                if (Q.pending) {
-                    Q.pending = false;
-                    bool end_path;
-                    if (best.obj < 0) {
-                        end_path = true;
-                        if (SIG) P.sig = sig_end_miss(P.sig, P.rng);
-                    } else {
-                        if (SIG) P.sig = sig_hit(P.sig, best.t, best.obj);
-                        Surf s;
-                        resolve_hit(S, best, P.o, P.d, s);
-                        P.L = mk3(P.L.x + P.T.x * s.emission.x, P.L.y + P.T.y * s.emission.y, P.L.z + P.T.z * s.emission.z);
-                        P.depth++;
-                        if (P.depth >= C.path_depth) {
-                            end_path = true;
-                            if (SIG) P.sig = sig_end_depth(P.sig);
-                        } else {
-                            f3 nd, w;
-                            scatter(s, P.d, P.rng, nd, w);
-                            P.o = s.p; P.d = nd;
-                            P.T = mk3(P.T.x * w.x, P.T.y * w.y, P.T.z * w.z);
-                            end_path = false;
-                        }
-                    }
-                    if (end_path) {
-                        Q.accum = Q.accum + P.L;
-                        if (SIG) Q.sigsum += P.sig;
-                        Q.sample++;
-                        Q.fresh = true;
-                    }
-                }
-                // ---- (b) Camera::generate_rays for the next sample, or retire the pixel ----
-                if (Q.fresh) {
-                    if (Q.sample >= spp) {
-                        // per-pixel mean (tracing.rs:241); pixels outside the image are written as 0
-                        float n = (float)C.spp;
-                        float* o3 = A.out + (size_t)out_idx * 3;
-                        if (spp != 0u) { o3[0] = Q.accum.x / n; o3[1] = Q.accum.y / n; o3[2] = Q.accum.z / n; }
-                        else { o3[0] = 0.0f; o3[1] = 0.0f; o3[2] = 0.0f; }
-                        if (SIG && A.sig) A.sig[out_idx] = spp != 0u ? Q.sigsum : 0u;
-                        Q.state = ST_DEAD;
-                    } else {
-                        rng_init(P.rng, A.seed_key, pixel, Q.sample);
-                        generate_ray(C, px, py, Q.sample, P.rng, P.o, P.d);
-                        P.T = mk3(1.0f, 1.0f, 1.0f); P.L = mk3(0.0f, 0.0f, 0.0f); P.depth = 0; P.sig = 0;
-                        Q.fresh = false;
-                    }
-                }
-                // ---- (c) Scene::intersect_ray: the object list, then the mesh roots ----
-                if (Q.state == ST_A) {
-                    best.obj = -1; best.t = 0.0f; best.tri = -1; best.u = best.v = 0.0f;
-                    intersect_list(S, P.o, P.d, t_min, t_max, P.rng, best);
-                    Q.tm = 0;
-                    if (enter_next_mesh(S, B, Q.tm, P.o, P.d, t_min, t_max, Q.too, Q.tod, Q.tinv, Q.ti, Q.tend, Q.ttb)) {
-                        Q.state = ST_TRAV; Q.tbt = t_max; Q.tbtri = -1; Q.tbu = Q.tbv = 0.0f;
-                    } else {
-                        Q.pending = true;
-                    }
-                }
-            }
-        } else {
-            if (DIAG) dg_tripsB++;
-            // ---- B-trip: BVHNode::intersect_ray (geometry.rs:94-119), k_steps voted micro-steps ----
-            for (int k = 0; k < k_steps; k++) {
-                const bool in_t = (Q.state == ST_TRAV);
-                float4 n0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), n1 = n0;
-                int tri = -1;
-                if (in_t) { B.node(Q.ti, n0, n1); tri = __float_as_int(n1.w); }
-                const bool at_leaf = in_t && tri >= 0, at_inner = in_t && tri < 0;
-                const int n_leaf = __popcll(__ballot(at_leaf)), n_inner = __popcll(__ballot(at_inner));
-                if (n_leaf + n_inner == 0) break;
-                if (n_inner >= n_leaf) {
-                    if (DIAG) { dg_tripsI++; dg_lanesI += (unsigned long long)n_inner; }
-                    if (at_inner) {
-                        bool hit = slab(mk3(n0.x, n0.y, n0.z), mk3(n1.x, n1.y, n1.z), Q.too, Q.tinv, t_min, Q.tbt);   // :103
-                        Q.ti = hit ? Q.ti + 1 : __float_as_int(n0.w);
-                    }
-                } else {
-                    if (DIAG) { dg_tripsL++; dg_lanesL += (unsigned long long)n_leaf; }
-                    if (at_leaf) {
-                        f3 a, e1, e2;
-                        B.tri(Q.ttb + tri, a, e1, e2);
-                        float t, u, v;
-                        if (tri_t(Q.too, Q.tod, a, e1, e2, t_min, Q.tbt, t, u, v)) {                                  // :97
-                            Q.tbt = t; Q.tbtri = tri; Q.tbu = u; Q.tbv = v;
-                        }
-                        Q.ti = Q.ti + 1;
-                    }
-                }
-                if (in_t && Q.ti >= Q.tend) {
-                    if (Q.tbtri >= 0) consider(best, Q.tbt, S.meshes[Q.tm].object_index, Q.tbtri, Q.tbu, Q.tbv);
-                    Q.tm++;
-                    if (enter_next_mesh(S, B, Q.tm, P.o, P.d, t_min, t_max, Q.too, Q.tod, Q.tinv, Q.ti, Q.tend, Q.ttb)) {
-                        Q.tbt = t_max; Q.tbtri = -1; Q.tbu = Q.tbv = 0.0f;
-                    } else {
-                        Q.state = ST_A; Q.pending = true;
-                    }
-                }
-            }
-        }
-    }
-
-    if (DIAG && A.diag && lane == 0) {
-        atomicAdd(&A.diag[0], dg_tripsA); atomicAdd(&A.diag[1], dg_lanesA);
-        atomicAdd(&A.diag[2], dg_tripsI); atomicAdd(&A.diag[3], dg_lanesI);
-        atomicAdd(&A.diag[4], dg_tripsL); atomicAdd(&A.diag[5], dg_lanesL);
-        atomicAdd(&A.diag[6], dg_tripsB); atomicAdd(&A.diag[7], 1ull);
     }
 }
 
@@ -1952,8 +1664,12 @@ __global__ __launch_bounds__(256) void wf_prefix(uint32_t* __restrict__ out_coun
                                                  uint32_t* __restrict__ trav_pfx, uint32_t* __restrict__ hdr,
                                                  volatile uint32_t* host_hdr, uint32_t seq) {
     __shared__ uint32_t sc[4][256];
+    __shared__ uint32_t tot_b;
     const uint32_t t = threadIdx.x;
+    if (t == 0) tot_b = 0;
+    __syncthreads();
     const uint32_t a = out_count[t], b = out_count[kWfShards + t], q = trav_count[t];
+    atomicAdd(&tot_b, b);
     out_count[t] = 0; out_count[kWfShards + t] = 0; trav_count[t] = 0;       // ready for the next wf_main
     if (t == 0) trav_count[kWfShards] = 0;                                  // trav_head, the walkers' shared cursor
     in_count[t] = a; in_count[kWfShards + t] = b;
@@ -1979,7 +1695,7 @@ __global__ __launch_bounds__(256) void wf_prefix(uint32_t* __restrict__ out_coun
         hdr[0] = blocks_a + x1; hdr[1] = x3; hdr[2] = x2; hdr[3] = 0;
         // the host's copy goes straight into pinned host memory (no copy kernel that would queue behind the
         // persistent walkers): data, system-scope fence, then the sequence number the host polls
-        host_hdr[0] = blocks_a + x1; host_hdr[1] = x3; host_hdr[2] = x2;
+        host_hdr[0] = blocks_a + x1; host_hdr[1] = x3; host_hdr[2] = x2; host_hdr[4] = tot_b;     // [4]: class-B paths (statistics only)
         __threadfence_system();
         host_hdr[3] = seq;
     }
@@ -2064,17 +1780,11 @@ __global__ __launch_bounds__(256) void fb_tonemap_u8(const float* __restrict__ i
 }
 
 // ---------------------------------------------------------------- launch wrappers
-hipError_t launch_megakernel(const K1Args& args, uint32_t n_blocks, bool lds, bool park, bool sig,
-                             size_t lds_bytes, hipStream_t stream) {
+hipError_t launch_megakernel(const K1Args& args, uint32_t n_blocks, bool lds, bool sig, size_t lds_bytes, hipStream_t stream) {
     dim3 grid(n_blocks), block(kBlock);
-#define PT_LAUNCH(L, P, G) hipLaunchKernelGGL((pt_megakernel<L, P, G>), grid, block, (L) ? lds_bytes : 0, stream, args)
-    if (lds) {
-        if (park) { if (sig) PT_LAUNCH(true, true, true); else PT_LAUNCH(true, true, false); }
-        else      { if (sig) PT_LAUNCH(true, false, true); else PT_LAUNCH(true, false, false); }
-    } else {
-        if (park) { if (sig) PT_LAUNCH(false, true, true); else PT_LAUNCH(false, true, false); }
-        else      { if (sig) PT_LAUNCH(false, false, true); else PT_LAUNCH(false, false, false); }
-    }
+#define PT_LAUNCH(L, G) hipLaunchKernelGGL((pt_megakernel<L, G>), grid, block, (L) ? lds_bytes : 0, stream, args)
+    if (lds) { if (sig) PT_LAUNCH(true, true); else PT_LAUNCH(true, false); }
+    else     { if (sig) PT_LAUNCH(false, true); else PT_LAUNCH(false, false); }
 #undef PT_LAUNCH
     return hipGetLastError();
 }
@@ -2088,20 +1798,6 @@ hipError_t launch_megakernel_voted(const K1Args& args, uint32_t n_blocks, bool l
     else          { if (sig) PT_LAUNCH_V(false, true, false); else PT_LAUNCH_V(false, false, false); }
 #undef PT_LAUNCH_V
     return hipGetLastError();
-}
-
-hipError_t launch_megakernel_pooled(const K1Args& args, uint32_t tiles_padded, bool lds, bool sig, bool diag,
-                                    size_t lds_bytes, hipStream_t stream) {
-    dim3 grid(tiles_padded * (uint32_t)(kTilePixels / (kBlock * kV))), block(kBlock);
-#define PT_LAUNCH_P(L, G, D) hipLaunchKernelGGL((pt_megakernel_pooled<L, G, D>), grid, block, (L) ? lds_bytes : 0, stream, args)
-    if (diag) { if (lds) PT_LAUNCH_P(true, true, true); else PT_LAUNCH_P(false, true, true); }
-    else if (lds) { if (sig) PT_LAUNCH_P(true, true, false); else PT_LAUNCH_P(true, false, false); }
-    else          { if (sig) PT_LAUNCH_P(false, true, false); else PT_LAUNCH_P(false, false, false); }
-#undef PT_LAUNCH_P
-    return hipGetLastError();
-}
-size_t pooled_park_bytes(uint32_t tiles_padded) {
-    return (size_t)tiles_padded * (size_t)(kTilePixels / (kBlock * kV)) * kV * kParkQ * kBlock * sizeof(float4);
 }
 
 hipError_t launch_phong(const K1Args& a, uint32_t n_blocks, bool sig, hipStream_t stream) {
@@ -2122,14 +1818,15 @@ hipError_t launch_wf_main(const WfArgs& a, uint32_t n_blocks, bool sig, hipStrea
     else hipLaunchKernelGGL((wf_main<false, false>), grid, block, 0, stream, a);
     return hipGetLastError();
 }
-hipError_t launch_wf_trav(const WfArgs& a, uint32_t n_blocks, int lds_mode, size_t lds_bytes, hipStream_t stream) {
+// big_lds_enabled: the calling context's record of the > 64 KB dynamic-LDS opt-in.  The attribute belongs to the
+// function ON THE CURRENT DEVICE, so it is kept per context (one context = one device), not per process.
+hipError_t launch_wf_trav(const WfArgs& a, uint32_t n_blocks, int lds_mode, size_t lds_bytes, bool* big_lds_enabled, hipStream_t stream) {
     dim3 grid(n_blocks), block(kBlock);
     if (lds_mode == 3) {           // nodes in LDS, one 1024-thread block per CU
-        static bool attr_set = false;
-        if (!attr_set) {           // > 64 KB of dynamic LDS needs the opt-in
+        if (!*big_lds_enabled) {
             hipError_t e = hipFuncSetAttribute((const void*)wf_trav<2, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return e;
-            attr_set = true;
+            *big_lds_enabled = true;
         }
         hipLaunchKernelGGL((wf_trav<2, 1024>), grid, dim3(1024), lds_bytes, stream, a);
     }

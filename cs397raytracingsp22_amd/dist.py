@@ -75,13 +75,14 @@ class TiledRenderer:
     torch supplies device memory, the stream and the collective; all compute is the HIP library."""
 
     def __init__(self, ctx, camera, rank: int = 0, world: int = 1, device: Optional[str] = None,
-                 variant: int = abi.MI_VARIANT_DEFAULT):
+                 variant: int = abi.MI_VARIANT_DEFAULT, flags: int = 0, max_state_bytes: int = 0):
         import torch
         if not torch.cuda.is_available():
             raise RuntimeError("torch cannot see the GPU: import torch BEFORE creating a Context "
                                "(its bundled HIP runtime must be the first one loaded into the process)")
         self.torch = torch
         self.ctx, self.cam, self.rank, self.world, self.variant = ctx, camera, rank, world, variant
+        self.flags, self.max_state_bytes = flags, max_state_bytes
         self.device = torch.device(device if device is not None else f"cuda:{ctx.device}")
         W, H = camera.screen_width, camera.screen_height
         self.padded = tiles_padded(W, H, world)
@@ -91,13 +92,14 @@ class TiledRenderer:
             self.image = torch.empty((H, W, 3), dtype=torch.float32, device=self.device)
             self.u8 = torch.empty((H, W, 3), dtype=torch.uint8, device=self.device)
         self.kernel_ms = []
-        ctx.reserve(camera, world)          # HBM for the wavefront path state: allocated here, not in the first frame
+        ctx.reserve(camera, world, max_state_bytes)          # HBM for the wavefront path state: allocated here, not in the first frame
 
     def render_frame(self, seed: int = 1, time_kernel: bool = False):
         torch = self.torch
         stream = torch.cuda.current_stream(self.device).cuda_stream
         st = self.ctx.render_tiles_device(self.cam, self.compact.data_ptr(), None, seed=seed, rank=self.rank,
-                                          world=self.world, stream=stream, variant=self.variant)
+                                          world=self.world, stream=stream, variant=self.variant, flags=self.flags,
+                                          max_state_bytes=self.max_state_bytes)
         if time_kernel:
             self.kernel_ms.append(self.ctx.last_kernel_ms())
         gathered = gather_compact(self.compact, self.world, self.rank)

@@ -83,11 +83,12 @@ class Context:
         abi.check(self._lib.mi_scene_upload(self._h, C.byref(flat.desc)))
 
     def render(self, cam: Camera, seed: int = 1, want_f32=True, want_u8=True, want_sig=False,
-               variant: int = abi.MI_VARIANT_DEFAULT):
+               variant: int = abi.MI_VARIANT_DEFAULT, flags: int = 0, max_state_bytes: int = 0):
         """mi_render: whole image on this GPU.  Returns (f32 [H,W,3] | None, u8 [H,W,3] | None,
         sig [H,W] | None, mi_stats)."""
         pod = cam.to_pod()
-        opts = abi.mi_render_opts(seed=seed, rank=0, world=1, variant=variant, want_signature=int(want_sig))
+        opts = abi.mi_render_opts(seed=seed, rank=0, world=1, variant=variant, want_signature=int(want_sig),
+                                  flags=flags, max_state_bytes=max_state_bytes)
         H, W = cam.screen_height, cam.screen_width
         f32 = np.empty((H, W, 3), np.float32) if want_f32 else None
         u8 = np.empty((H, W, 3), np.uint8) if want_u8 else None
@@ -103,10 +104,10 @@ class Context:
     # ---- device-pointer building blocks (multi-GPU; pointers are ints, e.g. tensor.data_ptr()) ----
     def render_tiles_device(self, cam: Camera, d_compact: int, d_sig: Optional[int] = None, seed: int = 1,
                             rank: int = 0, world: int = 1, stream: Optional[int] = None,
-                            variant: int = abi.MI_VARIANT_DEFAULT):
+                            variant: int = abi.MI_VARIANT_DEFAULT, flags: int = 0, max_state_bytes: int = 0):
         pod = cam.to_pod()
         opts = abi.mi_render_opts(seed=seed, rank=rank, world=world, variant=variant,
-                                  want_signature=int(d_sig is not None))
+                                  want_signature=int(d_sig is not None), flags=flags, max_state_bytes=max_state_bytes)
         st = abi.mi_stats()
         abi.check(self._lib.mi_render_tiles_device(self._h, C.byref(pod), C.byref(opts), d_compact, d_sig,
                                                    stream, C.byref(st)))
@@ -114,13 +115,14 @@ class Context:
 
     def render_samples_device(self, cam: Camera, sample_begin: int, sample_end: int, d_accum: int,
                               d_compact: Optional[int] = None, d_sig: Optional[int] = None, seed: int = 1,
-                              rank: int = 0, world: int = 1, stream: Optional[int] = None):
+                              rank: int = 0, world: int = 1, stream: Optional[int] = None,
+                              flags: int = 0, max_state_bytes: int = 0):
         """mi_render_samples_device: add samples [sample_begin, sample_end) of every pixel, in order, to the
         caller-held accumulator (float4 per compact pixel).  The call that reaches aa_sample_count also
         writes the means to d_compact.  Progressive display and checkpoint / resume are built on this."""
         pod = cam.to_pod()
         opts = abi.mi_render_opts(seed=seed, rank=rank, world=world, variant=abi.MI_VARIANT_DEFAULT,
-                                  want_signature=int(d_sig is not None))
+                                  want_signature=int(d_sig is not None), flags=flags, max_state_bytes=max_state_bytes)
         st = abi.mi_stats()
         abi.check(self._lib.mi_render_samples_device(self._h, C.byref(pod), C.byref(opts), sample_begin, sample_end,
                                                      d_accum, d_compact, d_sig, stream, C.byref(st)))
@@ -134,16 +136,23 @@ class Context:
         pod = cam.to_pod()
         abi.check(self._lib.mi_tonemap_device(self._h, C.byref(pod), d_image_f32, d_image_u8, stream))
 
-    def reserve(self, cam: Camera, world: int = 1):
+    def reserve(self, cam: Camera, world: int = 1, max_state_bytes: int = 0):
         """Allocate the wavefront pipeline's HBM buffers ahead of the first render (mi_reserve)."""
         pod = cam.to_pod()
-        abi.check(self._lib.mi_reserve(self._h, C.byref(pod), world))
+        abi.check(self._lib.mi_reserve(self._h, C.byref(pod), world, max_state_bytes))
 
     def last_pipeline_ms(self):
         """Wavefront pipeline of the last render: dict of per-kernel duration sums (ms) and launch count."""
         out = (C.c_float * 4)()
         abi.check(self._lib.mi_last_pipeline_ms(self._h, out))
         return {"wf_main_ms": float(out[0]), "wf_trav_ms": float(out[1]), "wf_reduce_ms": float(out[2]), "launches": int(out[3])}
+
+    def last_pipeline_counts(self):
+        """Path counts of the last wavefront render (mi_last_pipeline_counts), for traffic accounting."""
+        out = (C.c_uint64 * 8)()
+        abi.check(self._lib.mi_last_pipeline_counts(self._h, out))
+        k = ["passes", "paths_a", "paths_b", "queue_entries", "sample_slots", "pixels"]
+        return dict(zip(k, [int(v) for v in out]))
 
     def last_diag(self):
         """Counters of the last MI_VARIANT_VOTED_DIAG launch as a dict (diagnostic)."""

@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define MI_RT_ABI_VERSION 2
+#define MI_RT_ABI_VERSION 3
 
 /* ---- status codes (reference: panics via assert!/expect/unwrap, geometry.rs:149-151) ---- */
 typedef enum mi_status {
@@ -175,16 +175,25 @@ typedef struct mi_render_opts {
     int32_t  world;             /* number of ranks sharing the image (>=1)               */
     int32_t  variant;           /* 0 = default kernel; see mi_variant                    */
     int32_t  want_signature;    /* 1 = also produce per-pixel path signatures (diagnostic) */
-} mi_render_opts;
+    uint32_t flags;             /* MI_OPT_* bits, 0 = defaults                           */
+    uint64_t max_state_bytes;   /* wavefront pipeline: upper bound on the HBM it may hold for path state, queues and
+                                 * sample slots (0 = 60 % of the free HBM: a whole 1080p/256 spp frame is one 112 GB
+                                 * batch).  A smaller budget means more, smaller sample batches: same image, bit for
+                                 * bit, lower throughput (256 M / 64 M / 16 M paths per batch: 161 / 187 / 257 ms on cfg2) */
+} mi_render_opts;               /* 32 bytes */
+
+#define MI_OPT_NO_TILE_MASKS   1u   /* camera rays test every Scene.objects entry (no per-tile frustum masks): same image */
+#define MI_OPT_REFERENCE_WALK  2u   /* meshes: walk the reference's own BVH (geometry.rs:94-119) node by node even where the
+                                     * exact two-stage traversal would be used: same image, slower on large meshes */
+#define MI_OPT_TWO_STAGE       4u   /* meshes: use the two-stage traversal for every mesh, whatever its size: same image */
 
 typedef enum mi_variant {
     MI_VARIANT_DEFAULT    = 0,  /* library picks (currently MI_VARIANT_WAVEFRONT)                  */
-    MI_VARIANT_SIMPLE     = 1,  /* one segment per loop trip, mesh traversal in line               */
-    MI_VARIANT_PARKED     = 2,  /* mesh rays parked, traversed together when a __ballot vote says so */
+    MI_VARIANT_SIMPLE     = 1,  /* one segment per loop trip, mesh traversal in line (structural cross-check) */
+    /* 2 was MI_VARIANT_PARKED: removed in ABI 3 (documented slower)            */
     MI_VARIANT_VOTED      = 3,  /* per-lane state machine; every BVH node step is a __ballot-voted phase */
     MI_VARIANT_VOTED_DIAG = 4,  /* VOTED + per-phase trip / active-lane counters (never timed)      */
-    MI_VARIANT_POOLED     = 5,  /* VOTED with two path slots per lane (one parked in L2); experimental, slower */
-    MI_VARIANT_POOLED_DIAG = 6, /* POOLED + counters (never timed)                                  */
+    /* 5, 6 were MI_VARIANT_POOLED(_DIAG): removed in ABI 3                                          */
     MI_VARIANT_WAVEFRONT  = 7,  /* path state streamed through HBM, one kernel per phase (K1w); synchronises the stream */
     MI_VARIANT_RECURSIVE  = 8   /* shade_ray as written (tracing.rs:300-324), recursion on a per-lane stack: the only variant for
                                  * path_samples != 1 (chosen automatically); slow, bit-identical f32 image to the CPU restatement */
@@ -259,12 +268,19 @@ int  mi_last_kernel_ms(mi_ctx* ctx, float* ms);
 
 /* Size and allocate the wavefront pipeline's HBM buffers (path state, queue, sample slots) for
  * this camera with the image shared by `world` ranks, so that the first render does not pay the
- * allocation (about 112 GB for a whole 1080p / 256 spp frame on one GPU).  Optional. */
-int  mi_reserve(mi_ctx* ctx, const mi_camera_desc* cam, int32_t world);
+ * allocation (about 112 GB for a whole 1080p / 256 spp frame on one GPU).  `max_state_bytes` as in
+ * mi_render_opts (0 = 60 % of the free HBM).  Optional. */
+int  mi_reserve(mi_ctx* ctx, const mi_camera_desc* cam, int32_t world, uint64_t max_state_bytes);
 
 /* Wavefront pipeline (MI_VARIANT_WAVEFRONT) of the most recent render: out4 = { sum of wf_main
  * launch durations, of wf_trav, of wf_reduce (ms, HIP events around every launch), launches }. */
 int  mi_last_pipeline_ms(mi_ctx* ctx, float* out4);
+
+/* Path counts of the most recent wavefront render, for traffic accounting: out8 = { passes (wf_main launches
+ * that left survivors or ended the batch), class-A paths written to (and read back from) the HBM path state summed
+ * over the passes, class-B paths likewise, traversal-queue entries, sample slots, compact pixels, 0, 0 }.
+ * The bytes these stand for (72 B per class-A path and direction, 76 B per class-B path, ...) are in DESIGN.md. */
+int  mi_last_pipeline_counts(mi_ctx* ctx, uint64_t* out8);
 
 /* Counters of the most recent *_DIAG launch (synchronises the device):
  * out16 = { A trips, sum of lanes in A trips, interior-step trips, lanes, leaf-step trips,

@@ -39,27 +39,39 @@ def usable_cores():
 
 
 def build(force=False):
-    """Compile the oracle with gcc (oracle/Makefile)."""
-    # always ask make: it rebuilds when a source or include/mi_rt.h is newer than the library (an ABI change
-    # must never meet a stale oracle) and does nothing otherwise
+    """Compile the oracle with gcc (oracle/Makefile).  A failed build is an error even when an older
+    library exists: a source or ABI change that does not compile must never be validated against a stale oracle."""
     if os.environ.get("ORC_LIB"):
         return
     try:
-        subprocess.run(["make", "-C", _HERE] + (["-B"] if force else []), check=True, capture_output=True)
-    except (OSError, subprocess.CalledProcessError):
-        if not os.path.exists(LIB_PATH):
+        subprocess.run(["make", "-C", _HERE] + (["-B"] if force else []), check=True, capture_output=True, text=True)
+    except FileNotFoundError:
+        # no `make` on this host: accept a library that is newer than every source it was built from
+        srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".c", ".h"))]
+        srcs.append(os.path.join(os.path.dirname(_HERE), "include", "mi_rt.h"))
+        if not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(f) for f in srcs):
             raise
+    except subprocess.CalledProcessError as e:
+        raise RuntimeError(f"building the oracle failed:\n{e.stdout}\n{e.stderr}") from e
+
+
+def build_native():
+    """Second build of the same sources for TIMING only (bench.py cpu_baseline): -O3 -march=native on the host it
+    runs on.  Parity always uses the portable liborc.so.  Returns the library path."""
+    subprocess.run(["make", "-C", _HERE, "native"], check=True, capture_output=True, text=True)
+    return os.path.join(_HERE, "_build", "liborc_native.so")
 
 
 _lib = None
 
 
-def load():
+def load(path=None):
+    """The portable oracle library (cached), or — with `path` — another build of the same sources (not cached)."""
     global _lib
-    if _lib is None:
-        if not os.path.exists(LIB_PATH):
+    if _lib is None or path is not None:
+        if path is None and not os.path.exists(LIB_PATH):
             build()
-        lib = C.CDLL(LIB_PATH)
+        lib = C.CDLL(path or LIB_PATH)
         vp = C.c_void_p
         fp = C.POINTER(C.c_float)
         lib.orc_scene_create.argtypes = [C.POINTER(abi.mi_scene_desc), C.POINTER(vp)]
@@ -90,6 +102,8 @@ def load():
         lib.orc_rng_words.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, vp]
         lib.orc_rng_words.restype = None
         lib.orc_bvh_stats.argtypes = [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        if path is not None:
+            return lib
         _lib = lib
     return _lib
 
@@ -101,8 +115,8 @@ def _f3(v):
 class OracleScene:
     """An orc_scene built from the same flattened description the product consumes."""
 
-    def __init__(self, flat):
-        self._lib = load()
+    def __init__(self, flat, lib=None):
+        self._lib = lib if lib is not None else load()
         self._flat = flat
         self._h = C.c_void_p()
         rc = self._lib.orc_scene_create(C.byref(flat.desc), C.byref(self._h))

@@ -29,7 +29,7 @@ use std::os::raw::{c_char, c_int, c_void};
     pub path_depth: u32, pub path_samples: u32, pub screen_width: u32, pub screen_height: u32,
     pub focal_length: f32, pub focus_dist: f32, pub lens_radius: f32, pub aa_sample_count: u32, pub max_trace_dist: f32, pub gamma: f32,
 }
-#[repr(C)] pub struct mi_render_opts { pub seed: u32, pub rank: i32, pub world: i32, pub variant: i32, pub want_signature: i32 }
+#[repr(C)] #[derive(Default)] pub struct mi_render_opts { pub seed: u32, pub rank: i32, pub world: i32, pub variant: i32, pub want_signature: i32, pub flags: u32, pub max_state_bytes: u64 }
 #[repr(C)] #[derive(Default)] pub struct mi_stats { pub samples: u64, pub pixels: u64, pub tiles: u32, pub tiles_padded: u32, pub kernel_ms: f32, pub total_ms: f32, pub scene_bytes: u32, pub scene_in_lds: u32 }
 pub enum mi_ctx {}
 

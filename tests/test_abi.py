@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     lib = abi.load()
     for name in declared_functions():
         assert hasattr(lib, name), name
-    assert lib.mi_abi_version() == abi.MI_RT_ABI_VERSION == 2
+    assert lib.mi_abi_version() == abi.MI_RT_ABI_VERSION == 3
 
 
 def test_ctypes_layout_matches_c(tmp_path):

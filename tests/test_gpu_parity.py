@@ -38,12 +38,12 @@ def compare(ctx, orc, sc, seed=1, variant=abi.MI_VARIANT_DEFAULT, window=None):
     return st
 
 
-@pytest.mark.parametrize("variant", [abi.MI_VARIANT_SIMPLE, abi.MI_VARIANT_PARKED, abi.MI_VARIANT_VOTED, abi.MI_VARIANT_POOLED, abi.MI_VARIANT_WAVEFRONT])
+@pytest.mark.parametrize("variant", [abi.MI_VARIANT_SIMPLE, abi.MI_VARIANT_VOTED, abi.MI_VARIANT_WAVEFRONT])
 def test_config1_cornell(gpu_ctx, orc, variant):
     compare(gpu_ctx, orc, scenes.config1(128, 128, 16, 8), variant=variant)
 
 
-@pytest.mark.parametrize("variant", [abi.MI_VARIANT_SIMPLE, abi.MI_VARIANT_PARKED, abi.MI_VARIANT_VOTED, abi.MI_VARIANT_POOLED, abi.MI_VARIANT_WAVEFRONT])
+@pytest.mark.parametrize("variant", [abi.MI_VARIANT_SIMPLE, abi.MI_VARIANT_VOTED, abi.MI_VARIANT_WAVEFRONT])
 def test_config2_teapot(gpu_ctx, orc, variant):
     compare(gpu_ctx, orc, scenes.config2(160, 96, 16, 10), variant=variant)
 

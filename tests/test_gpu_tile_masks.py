@@ -2,11 +2,10 @@
 32x32 tile, the list entries a conservative host-side frustum test proves unreachable.  Skipping must
 never change a path: random scenes of many small objects under random (also skewed, non-unit) camera
 bases, checked bit for bit against the oracle and against the same render with masking switched off."""
-import os
-
 import numpy as np
 import pytest
 
+from cs397raytracingsp22_amd import abi  # noqa: E402
 from cs397raytracingsp22_amd import (Camera, ConvexVolume, Dielectric, Isotropic, Lambertian, Metal, Plane, Scene, Sphere,
                                      StaticMesh, Triangle, cgmath, scenes)
 
@@ -52,11 +51,7 @@ def test_masked_primary_rays_take_the_oracles_paths(gpu_ctx, orc, seed):
     r32, _, rsig, _ = orc.OracleScene(flat).render(sc.camera, seed=seed, want_u8=False)
     assert int((sig != rsig).sum()) == 0
     assert float((np.abs(f32.astype(np.float64) - r32) / np.maximum(1.0, np.abs(r32))).max()) <= 2e-5
-    os.environ["MI_RT_NO_TILE_MASK"] = "1"                                # read by the library at every render
-    try:
-        g32, _, gsig, _ = gpu_ctx.render(sc.camera, seed=seed, want_u8=False, want_sig=True)
-    finally:
-        del os.environ["MI_RT_NO_TILE_MASK"]
+    g32, _, gsig, _ = gpu_ctx.render(sc.camera, seed=seed, want_u8=False, want_sig=True, flags=abi.MI_OPT_NO_TILE_MASKS)
     assert np.array_equal(gsig, sig) and np.array_equal(g32, f32)          # masking changes nothing, bit for bit
 
 
@@ -132,11 +127,7 @@ def test_every_tile_of_the_full_frames(gpu_ctx, name):
     gpu_ctx.upload(sc.flatten())
     f32, _, sig, _ = gpu_ctx.render(sc.camera, seed=21, want_u8=False, want_sig=True)
     fast, _, _, _ = gpu_ctx.render(sc.camera, seed=21, want_u8=False, want_sig=False)     # dead-tile shortcut live
-    os.environ["MI_RT_NO_TILE_MASK"] = "1"
-    try:
-        g32, _, gsig, _ = gpu_ctx.render(sc.camera, seed=21, want_u8=False, want_sig=True)
-    finally:
-        del os.environ["MI_RT_NO_TILE_MASK"]
+    g32, _, gsig, _ = gpu_ctx.render(sc.camera, seed=21, want_u8=False, want_sig=True, flags=abi.MI_OPT_NO_TILE_MASKS)
     assert np.array_equal(gsig, sig) and np.array_equal(g32, f32) and np.array_equal(fast, f32)
     assert int((sig != 0).sum()) > 0
 

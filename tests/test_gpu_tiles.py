@@ -76,7 +76,8 @@ def test_error_paths(gpu_ctx):
     gpu_ctx.upload(sc.flatten())
     cam = sc.camera
     for field, value, code in (("path_samples", 0, abi.MI_ERR_INVALID), ("shading_mode", 7, abi.MI_ERR_INVALID),
-                               ("projection_mode", -1, abi.MI_ERR_INVALID), ("aa_sample_count", 0, abi.MI_ERR_INVALID)):
+                               ("projection_mode", -1, abi.MI_ERR_INVALID), ("aa_sample_count", 0, abi.MI_ERR_INVALID),
+                               ("gamma", 0.0, abi.MI_ERR_INVALID), ("gamma", float("nan"), abi.MI_ERR_INVALID)):
         old = getattr(cam, field)
         setattr(cam, field, value)
         with pytest.raises(abi.MiError) as ei:
@@ -124,7 +125,7 @@ def test_run_module_writes_png(tmp_path):
     assert img.shape == (64, 64, 3) and img.max() > 100
 
 
-def test_wavefront_batching_is_exact(gpu_ctx, monkeypatch):
+def test_wavefront_batching_is_exact(gpu_ctx):
     """The wavefront pipeline splits the samples into batches when the path state does not fit
     in HBM.  Forcing small, uneven batches (spp 25 -> 7+7+7+4) must not change a single bit:
     samples are reduced in sample order whatever the batch boundaries are."""
@@ -134,11 +135,11 @@ def test_wavefront_batching_is_exact(gpu_ctx, monkeypatch):
     gpu_ctx.upload(flat)
     ref32, ref8, refsig, _ = gpu_ctx.render(sc.camera, seed=11, want_sig=True)
     npix = pdist.tiles_padded(160, 96, 1) * pdist.TILE_PIXELS
-    monkeypatch.setenv("MI_RT_WF_PATHS", str(npix * 7))
+    bytes_per_path = 2 * 6 * 16 + 4 + 16           # mi_rt.cpp kWfBytesPerPath: ping + pong state, queue word, sample slot
     small = Context(0)
     try:
         small.upload(flat)
-        f32, u8, sig, _ = small.render(sc.camera, seed=11, want_sig=True)
+        f32, u8, sig, _ = small.render(sc.camera, seed=11, want_sig=True, max_state_bytes=npix * 7 * bytes_per_path)
         assert small.last_pipeline_ms()["launches"] > gpu_ctx.last_pipeline_ms()["launches"]
     finally:
         small.close()
@@ -163,3 +164,78 @@ def test_config5_full_size_multibatch(gpu_ctx, orc):
     assert np.array_equal(sig[y0:y0 + h, x0:x0 + w], rsig)
     assert float(np.sqrt(np.mean((f32[y0:y0 + h, x0:x0 + w].astype(np.float64) - r32) ** 2))) <= 1e-3
     print(f"cfg5 full size: {st.samples / st.kernel_ms / 1e3:.0f} Msamples/s, kernel {st.kernel_ms:.0f} ms")
+
+
+def _assemble_with_signatures(ctx, cam, world, seed):
+    """Every rank's share in turn (as `assemble`), signatures included; K3 + K4 on the device, the signature plane
+    un-permuted with the numpy mirror of K3's mapping."""
+    import torch
+    dev = torch.device("cuda:0")
+    padded = pdist.tiles_padded(cam.screen_width, cam.screen_height, world)
+    gathered = torch.zeros((world, padded, pdist.TILE_PIXELS, 3), dtype=torch.float32, device=dev)
+    gsig = torch.zeros((world, padded, pdist.TILE_PIXELS), dtype=torch.int32, device=dev)
+    samples = 0
+    for r in range(world):
+        st = ctx.render_tiles_device(cam, gathered[r].data_ptr(), gsig[r].data_ptr(), seed=seed, rank=r, world=world, stream=None)
+        samples += st.samples
+    image = torch.empty((cam.screen_height, cam.screen_width, 3), dtype=torch.float32, device=dev)
+    u8 = torch.empty((cam.screen_height, cam.screen_width, 3), dtype=torch.uint8, device=dev)
+    ctx.unpermute_device(cam, world, gathered.data_ptr(), image.data_ptr())
+    ctx.tonemap_device(cam, image.data_ptr(), u8.data_ptr())
+    torch.cuda.synchronize(dev)
+    r_of, idx = pdist.compact_index(cam.screen_width, cam.screen_height, world)
+    sig = gsig.cpu().numpy().view(np.uint32).reshape(world, -1)[r_of, idx]
+    return image.cpu().numpy(), u8.cpu().numpy(), sig, samples
+
+
+def test_config3_full_size_eight_virtual_ranks(gpu_ctx, orc):
+    """BASELINE.json configs[2] as stated: 1920x1080, 1024 spp, the image tiled over 8 ranks (virtual: each rank's
+    255 tiles rendered in turn on this GPU through mi_render_tiles_device), one gathered buffer -> K3 -> K4.
+    Two windows against the oracle at the full 1024 spp (signatures bit-exact, RMS <= 1e-3), the whole frame finite and
+    inside the furnace bound, and the world-8 assembly equal to the one-rank image bit for bit."""
+    sc = scenes.config3()
+    cam = sc.camera
+    assert (cam.screen_width, cam.screen_height, cam.aa_sample_count) == (1920, 1080, 1024)
+    flat = sc.flatten()
+    gpu_ctx.upload(flat)
+    img, u8, sig, samples = _assemble_with_signatures(gpu_ctx, cam, 8, seed=1)
+    assert samples == 1920 * 1080 * 1024
+    assert np.isfinite(img).all() and img.min() >= 0.0 and img.max() <= 4.0 / (1 - 0.75 * 0.8) + 1e-3
+    assert (img[:, :300] == 0).all() and img[400:700, 800:1100].mean() > 0.1
+    o = orc.OracleScene(flat)
+    for win in ((930, 560, 16, 8), (1250, 905, 16, 8)):          # teapot body; floor under the glass sphere
+        x0, y0, w, h = win
+        r32, r8, rsig, _ = o.render(cam, seed=1, window=win)
+        assert np.array_equal(sig[y0:y0 + h, x0:x0 + w], rsig)
+        assert float(np.sqrt(np.mean((img[y0:y0 + h, x0:x0 + w].astype(np.float64) - r32) ** 2))) <= 1e-3
+        assert int(np.abs(u8[y0:y0 + h, x0:x0 + w].astype(int) - r8.astype(int)).max()) <= 1
+    one32, one8, onesig, st = gpu_ctx.render(cam, seed=1, want_sig=True)
+    assert st.samples == samples
+    assert np.array_equal(one32, img) and np.array_equal(one8, u8) and np.array_equal(onesig, sig)
+
+
+def test_config4_full_size(gpu_ctx, orc):
+    """BASELINE.json configs[3] as stated: textured drone (five 2048^2 maps: albedo, emission, metallic, roughness,
+    normal) in the Cornell box, 1920x1080, 256 spp.  Two windows on the drone against the oracle; the whole frame
+    with tile masks equals the frame without them, and the exact two-stage mesh traversal equals the plain walk of the
+    reference's tree, signatures and radiance, bit for bit."""
+    sc = scenes.config4()
+    cam = sc.camera
+    assert (cam.screen_width, cam.screen_height, cam.aa_sample_count) == (1920, 1080, 256)
+    flat = sc.flatten()
+    assert all(flat.desc.textures[i].width == 2048 for i in range(flat.desc.n_textures)) and flat.desc.n_textures == 5
+    gpu_ctx.upload(flat)
+    f32, u8, sig, st = gpu_ctx.render(cam, seed=1, want_sig=True)
+    assert st.samples == 1920 * 1080 * 256
+    assert np.isfinite(f32).all() and f32.min() >= 0.0
+    o = orc.OracleScene(flat)
+    for win in ((952, 560, 12, 6), (800, 640, 12, 6)):
+        x0, y0, w, h = win
+        r32, r8, rsig, _ = o.render(cam, seed=1, window=win)
+        assert np.array_equal(sig[y0:y0 + h, x0:x0 + w], rsig)
+        assert float(np.sqrt(np.mean((f32[y0:y0 + h, x0:x0 + w].astype(np.float64) - r32) ** 2))) <= 1e-3
+        assert int(np.abs(u8[y0:y0 + h, x0:x0 + w].astype(int) - r8.astype(int)).max()) <= 1
+    for flags in (abi.MI_OPT_NO_TILE_MASKS, abi.MI_OPT_REFERENCE_WALK, abi.MI_OPT_TWO_STAGE):
+        g32, _, gsig, _ = gpu_ctx.render(cam, seed=1, want_u8=False, want_sig=True, flags=flags)
+        assert np.array_equal(gsig, sig) and np.array_equal(g32, f32), flags
+    print(f"cfg4 full size: {st.samples / st.kernel_ms / 1e3:.0f} Msamples/s, kernel {st.kernel_ms:.0f} ms")

@@ -51,5 +51,10 @@ if __name__ == "__main__":
         measure("cfg1", scenes.config1(), bands=8, rows=8)
     if "cfg2" in which:
         measure("cfg2", scenes.config2(), bands=8, rows=2)
+    # the counters are per camera sample: a lower spp than the configuration's measures the same ratios
+    if "cfg4" in which:
+        measure("cfg4", scenes.config4(spp=16), bands=8, rows=2)
     if "cfg5" in which:
         measure("cfg5", scenes.config5(spp=64), bands=8, rows=2)
+    if "head" in which:
+        measure("head", scenes.head_scene(800, 800, 16, textures=scenes.load_asset_textures()), bands=8, rows=2)
