@@ -205,7 +205,7 @@ def main():
         r.render_frame(seed=1)
     barrier()
     t0 = time.perf_counter()
-    pipe = {"wf_main_ms": 0.0, "wf_trav_ms": 0.0, "wf_reduce_ms": 0.0, "launches": 0}
+    pipe = {"wf_main_ms": 0.0, "wf_trav_ms": 0.0, "wf_reduce_ms": 0.0, "launches": 0, "wf_trav_f_ms": 0.0, "wf_replay_ms": 0.0}
     counts = None
     for s in range(args.steps):
         r.render_frame(seed=1 + s, time_kernel=True)
@@ -270,7 +270,8 @@ def main():
                          "traffic_model_bytes": model_bytes, "path_counts": counts,
                          "kernel_ms": kernel_ms,
                          "per_step_ms": ({"wf_main": per_step["wf_main_ms"], "wf_trav": per_step["wf_trav_ms"],
-                                          "wf_reduce": per_step["wf_reduce_ms"], "launches": per_step["launches"]}
+                                          "wf_reduce": per_step["wf_reduce_ms"], "launches": per_step["launches"],
+                                          "wf_trav_f": per_step["wf_trav_f_ms"], "wf_replay": per_step["wf_replay_ms"]}
                                          if per_step["launches"] else None),
                          "valu": valu,
                          "algorithmic_bytes_per_sample": b_sample,

@@ -16,10 +16,10 @@ from . import abi  # noqa: F401
 from .materials import Dielectric, Isotropic, Lambertian, Material, Metal, ParameterizedMaterial  # noqa: F401
 from .geometry import ConvexVolume, Intersectable, Plane, Sphere, StaticMesh, Triangle  # noqa: F401
 from .texture import Texture  # noqa: F401
-from .tracing import Camera, CameraProjectionMode, Context, Scene, ShadingMode, compact_size  # noqa: F401
+from .tracing import Camera, CameraProjectionMode, Context, MultiContext, Scene, ShadingMode, compact_size  # noqa: F401
 
 __all__ = [
-    "abi", "Camera", "CameraProjectionMode", "ShadingMode", "Scene", "Context", "compact_size",
+    "abi", "Camera", "CameraProjectionMode", "ShadingMode", "Scene", "Context", "MultiContext", "compact_size",
     "Intersectable", "Sphere", "Triangle", "Plane", "ConvexVolume", "StaticMesh",
     "Material", "Lambertian", "Metal", "Dielectric", "ParameterizedMaterial", "Isotropic", "Texture",
 ]

@@ -28,6 +28,7 @@
 
 #include "../../include/mi_rt.h"
 #include "pt_device.h"
+#include "bvh_build.hpp"
 
 #pragma clang fp contract(off)
 
@@ -39,6 +40,8 @@ hipError_t launch_wf_main(const WfArgs& a, uint32_t n_blocks, bool sig, hipStrea
 hipError_t launch_phong(const K1Args& a, uint32_t n_blocks, bool sig, hipStream_t stream);
 hipError_t launch_branch(const K1Args& a, uint32_t n_blocks, uint32_t path_samples, bool sig, hipStream_t stream);
 hipError_t launch_wf_trav(const WfArgs& a, uint32_t n_blocks, int lds_mode, size_t lds_bytes, bool* big_lds_enabled, hipStream_t stream);
+hipError_t launch_wf_trav_f(const WfArgs& a, uint32_t n_blocks, hipStream_t stream);
+hipError_t launch_wf_replay(const WfArgs& a, uint32_t n_blocks, hipStream_t stream);
 hipError_t launch_wf_prefix(uint32_t* out_count, uint32_t* trav_count, uint32_t* in_count, uint32_t* in_blkpfx,
                             uint32_t* trav_pfx, uint32_t* hdr, uint32_t* host_hdr, uint32_t seq, hipStream_t stream);
 hipError_t launch_wf_reduce(const WfArgs& a, bool first_batch, bool last_batch, hipStream_t stream);
@@ -93,6 +96,11 @@ struct mi_ctx {
     DScene S{};
     bool have_scene = false;
     uint32_t lds_bytes = 0;                  // bytes needed to stage nodes + tris, 0 = no meshes
+    // per live mesh (Scene.objects order): end of its nodes in the node pool, does the two-stage bound apply to it at all,
+    // is it walked two-stage by default (qualifies and large enough for the F-tree to pay)
+    std::vector<int> mesh_node_end; std::vector<uint8_t> mesh_qualifies, mesh_default_ts;
+    void* d_cand = nullptr; size_t cand_bytes = 0;           // two-stage candidates [cap][kCandMax] {t, key}
+    void* d_cand_hdr = nullptr; size_t cand_hdr_bytes = 0;   // [cap] {pos, count | flags}
 
     // scratch for mi_render
     float* d_compact = nullptr; size_t compact_bytes = 0;
@@ -122,7 +130,7 @@ struct mi_ctx {
     std::vector<unsigned long long> h_tile_mask; void* d_tile_mask = nullptr; size_t tile_mask_bytes = 0;
     mi_camera_desc mask_cam{}; bool mask_valid = false;
     std::vector<hipEvent_t> wf_ev;                   // event pool for per-kernel timing of the pipeline
-    float wf_ms[4] = { 0, 0, 0, 0 };                 // last frame: wf_main, wf_trav, wf_reduce totals (ms), launches
+    float wf_ms[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };     // last frame: wf_main, wf_trav, wf_reduce totals (ms), launches, wf_trav_f, wf_replay
     int n_cus = 256;
     // Developer knobs (MI_RT_* environment variables), read ONCE in mi_ctx_create; none is needed for
     // normal operation and none changes a result — what a caller may want to control is in mi_render_opts.
@@ -228,6 +236,8 @@ extern "C" void mi_ctx_destroy(mi_ctx* c) {
     if (c->d_wf_q) (void)hipFree(c->d_wf_q);
     if (c->d_wf_samp) (void)hipFree(c->d_wf_samp);
     if (c->d_wf_acc) (void)hipFree(c->d_wf_acc);
+    if (c->d_cand) (void)hipFree(c->d_cand);
+    if (c->d_cand_hdr) (void)hipFree(c->d_cand_hdr);
     if (c->d_tile_mask) (void)hipFree(c->d_tile_mask);
     if (c->d_wf_cnt) (void)hipFree(c->d_wf_cnt);
     if (c->h_hdr) (void)hipHostFree(c->h_hdr);
@@ -243,56 +253,6 @@ extern "C" void mi_ctx_destroy(mi_ctx* c) {
 // ------------------------------------------------------------------ scene compiler
 namespace {
 
-struct Box { h3 mn, mx; };
-
-// IndexedTriangle::bounding_box geometry.rs:367-381
-Box tri_box(h3 a, h3 b, h3 c) {
-    Box r;
-    r.mn = H3(fminf(a.x, fminf(b.x, c.x)), fminf(a.y, fminf(b.y, c.y)), fminf(a.z, fminf(b.z, c.z)));
-    r.mx = H3(fmaxf(a.x, fmaxf(b.x, c.x)), fmaxf(a.y, fmaxf(b.y, c.y)), fmaxf(a.z, fmaxf(b.z, c.z)));
-    return r;
-}
-// AABB::aabb_surrounding geometry.rs:28-41
-Box surround(const Box& a, const Box& b) {
-    Box r;
-    r.mn = H3(fminf(a.mn.x, b.mn.x), fminf(a.mn.y, b.mn.y), fminf(a.mn.z, b.mn.z));
-    r.mx = H3(fmaxf(a.mx.x, b.mx.x), fmaxf(a.mx.y, b.mx.y), fmaxf(a.mx.z, b.mx.z));
-    return r;
-}
-
-struct MeshCompiler {
-    const mi_mesh* m;
-    std::vector<float>* nodes;     // 8 floats per node
-    int base;                      // index of this mesh's root in the node pool
-
-    h3 vpos(int tri, int corner) const { return H3p(&m->positions[3 * (size_t)m->indices[3 * (size_t)tri + corner]]); }
-
-    // StaticMesh::build_bvh_helper geometry.rs:190-217, emitted in DFS pre-order.
-    // The reference's random-axis sort (:200-207) only permutes a scratch vector whose
-    // entries are never read back (the leaf is built from `idx: start`, :194), so the
-    // tree is this index-range median split whatever the RNG does.
-    Box build(int start, int end) {
-        int me = (int)(nodes->size() / 8);
-        nodes->resize(nodes->size() + 8);
-        Box box;
-        int tri = -1;
-        if (end - start == 1) {                                         // :192
-            box = tri_box(vpos(start, 0), vpos(start, 1), vpos(start, 2));   // :195
-            tri = start;                                                // :194
-        } else {
-            int mid = start + (end - start) / 2;                        // :209
-            Box l = build(start, mid);                                  // :210
-            Box r = build(mid, end);                                    // :211
-            box = surround(l, r);                                       // :212
-        }
-        int skip = (int)(nodes->size() / 8);                            // first node after this subtree
-        float* n = &(*nodes)[(size_t)me * 8];
-        n[0] = box.mn.x; n[1] = box.mn.y; n[2] = box.mn.z; memcpy(&n[3], &skip, 4);
-        n[4] = box.mx.x; n[5] = box.mx.y; n[6] = box.mx.z; memcpy(&n[7], &tri, 4);
-        return box;
-    }
-};
-
 bool finite16(const float* m) { for (int i = 0; i < 16; i++) if (!std::isfinite(m[i])) return false; return true; }
 
 }  // namespace
@@ -307,7 +267,10 @@ extern "C" int mi_scene_upload(mi_ctx* c, const mi_scene_desc* d) {
     std::vector<DObject> objs((size_t)d->n_objects);
     std::vector<DMaterial> mats((size_t)d->n_materials);
     std::vector<DMesh> meshes((size_t)d->n_meshes);
-    std::vector<float> nodes, tris;
+    std::vector<DMeshF> meshf((size_t)d->n_meshes);
+    struct MeshBuild { std::vector<float> nodes, fnodes, ftris; bool qualifies = false, default_ts = false; };
+    std::vector<MeshBuild> mb((size_t)d->n_meshes);
+    std::vector<float> nodes, tris, fnodes, ftris;
     std::vector<DTriAttr> attrs;
     std::vector<DTexture> texs((size_t)d->n_textures);
     std::vector<uint8_t> texels;
@@ -359,13 +322,11 @@ extern "C" int mi_scene_upload(mi_ctx* c, const mi_scene_desc* d) {
             M.tex[k] = s.textures[k] < 0 ? -1 : s.textures[k];
         }
         M.object_index = -1;
-        M.node_begin = (int)(nodes.size() / 8);
         M.tri_begin = (int)(tris.size() / 12);
         M.n_tris = s.n_triangles;
-        MeshCompiler mc{ &s, &nodes, M.node_begin };
-        mc.build(0, s.n_triangles);                                     // geometry.rs:185
-        M.node_end = (int)(nodes.size() / 8);
-        // skip links are pool-absolute already (node indices are pool indices)
+        MeshBuild& B = mb[(size_t)mi];
+        build::RefTree rt{ s.positions, s.indices, &B.nodes };           // mesh-local node indices; relocated into the pool below
+        rt.build(0, s.n_triangles);                                      // geometry.rs:185
         for (int t = 0; t < s.n_triangles; t++) {
             uint32_t ia = s.indices[3 * (size_t)t], ib = s.indices[3 * (size_t)t + 1], ic = s.indices[3 * (size_t)t + 2];
             h3 a = H3p(&s.positions[3 * (size_t)ia]), b = H3p(&s.positions[3 * (size_t)ib]), cc = H3p(&s.positions[3 * (size_t)ic]);
@@ -381,6 +342,47 @@ extern "C" int mi_scene_upload(mi_ctx* c, const mi_scene_desc* d) {
             float den = (u2 - u1) * (v3 - v1) - (v2 - v1) * (u3 - u1);
             A.tan[0] = num.x / den; A.tan[1] = num.y / den; A.tan[2] = num.z / den;
             attrs.push_back(A);
+        }
+        // Two-stage traversal (bvh_build.hpp): does the padding bound apply to this mesh?  B = 7 eps E2 |d_obj| / 1e-4 must
+        // stay <= 1/2 for every ray; |d_obj| <= |inv_transform's 3x3|_F |d_world|, and world directions of up to 8 units are
+        // covered with a factor 10 to spare (a longer one takes the reference walk for that ray, decided on the device).
+        DMeshF& F = meshf[(size_t)mi];
+        memset(&F, 0, sizeof F);
+        {
+            build::FTree ft{ tris.data() + (size_t)M.tri_begin * 12, s.n_triangles, &B.fnodes, &B.ftris, 0, 2, {}, {}, {} };
+            const build::FConst fc = ft.run();
+            double fro = 0.0;
+            for (int cc = 0; cc < 3; cc++) for (int r = 0; r < 3; r++) fro += (double)s.inv_transform[cc * 4 + r] * (double)s.inv_transform[cc * 4 + r];
+            const double b_ref = 7.0 * 5.9604645e-08 * (double)fc.E2 * (std::sqrt(fro) * 8.0) * 1.0e4;
+            const bool affine = s.inv_transform[3] == 0.0f && s.inv_transform[7] == 0.0f && s.inv_transform[11] == 0.0f && s.inv_transform[15] == 1.0f;
+            B.qualifies = affine && std::isfinite(b_ref) && b_ref <= 0.05 && s.n_triangles < (1 << 24) && std::isfinite(fc.R) && std::isfinite(fc.L);
+            B.default_ts = B.qualifies && s.n_triangles >= 1024;        // below that the reference's tree sits in LDS and the F-tree does not pay
+            F.qualifies = B.qualifies ? 1 : 0;
+            F.E2 = fc.E2; F.L = fc.L; F.cx = fc.cx; F.cy = fc.cy; F.cz = fc.cz; F.R = fc.R;
+            if (!B.qualifies) { B.fnodes.clear(); B.ftris.clear(); }
+        }
+    }
+    // Pool placement: meshes walked through the reference's tree first, so that one LDS window over the head of the node
+    // pool covers exactly the trees wf_trav needs.  (The order of Scene.objects — ties, RNG draws — is not touched.)
+    {
+        std::vector<int> order;
+        for (int pass = 0; pass < 2; pass++)
+            for (int mi = 0; mi < d->n_meshes; mi++) if ((mb[(size_t)mi].default_ts ? 1 : 0) == pass) order.push_back(mi);
+        for (int mi : order) {
+            MeshBuild& B = mb[(size_t)mi];
+            DMesh& M = meshes[(size_t)mi];
+            DMeshF& F = meshf[(size_t)mi];
+            const int nbase = (int)(nodes.size() / 8), fbase = (int)(fnodes.size() / 8);
+            M.node_begin = nbase;
+            for (size_t k = 0; k < B.nodes.size(); k += 8) { int sk; memcpy(&sk, &B.nodes[k + 3], 4); sk += nbase; memcpy(&B.nodes[k + 3], &sk, 4); }
+            nodes.insert(nodes.end(), B.nodes.begin(), B.nodes.end());
+            M.node_end = (int)(nodes.size() / 8);
+            for (size_t k = 0; k < B.fnodes.size(); k += 8) { int sk; memcpy(&sk, &B.fnodes[k + 3], 4); sk += fbase; memcpy(&B.fnodes[k + 3], &sk, 4); }
+            F.fnode_begin = fbase; F.ftri_begin = (int)(ftris.size() / 12);
+            fnodes.insert(fnodes.end(), B.fnodes.begin(), B.fnodes.end());
+            ftris.insert(ftris.end(), B.ftris.begin(), B.ftris.end());
+            F.fnode_end = (int)(fnodes.size() / 8);
+            B.nodes.clear(); B.nodes.shrink_to_fit(); B.fnodes.clear(); B.ftris.clear();
         }
     }
 
@@ -446,8 +448,15 @@ extern "C" int mi_scene_upload(mi_ctx* c, const mi_scene_desc* d) {
     }
     // meshes that are not referenced by Scene.objects are not part of the scene
     std::vector<DMesh> live;
+    std::vector<DMeshF> livef;
+    c->mesh_node_end.clear(); c->mesh_qualifies.clear(); c->mesh_default_ts.clear();
     for (int i = 0; i < d->n_objects; i++)
-        if (objs[(size_t)i].kind == OBJ_MESH) { int r = objs[(size_t)i].ref; objs[(size_t)i].ref = (int)live.size(); live.push_back(meshes[(size_t)r]); }
+        if (objs[(size_t)i].kind == OBJ_MESH) {
+            int r = objs[(size_t)i].ref; objs[(size_t)i].ref = (int)live.size();
+            live.push_back(meshes[(size_t)r]); livef.push_back(meshf[(size_t)r]);
+            c->mesh_node_end.push_back(meshes[(size_t)r].node_end);
+            c->mesh_qualifies.push_back(mb[(size_t)r].qualifies ? 1 : 0); c->mesh_default_ts.push_back(mb[(size_t)r].default_ts ? 1 : 0);
+        }
 
     // kind-grouped copy of the non-mesh objects (stable within a kind)
     std::vector<DObject> list;
@@ -498,7 +507,10 @@ extern "C" int mi_scene_upload(mi_ctx* c, const mi_scene_desc* d) {
     size_t off_list = align(off_obj + objs.size() * sizeof(DObject));
     size_t off_mat = align(off_list + (list.size() + 1) * sizeof(DObject));      // +1: the loop prefetches one record ahead
     size_t off_mesh = align(off_mat + mats.size() * sizeof(DMaterial));
-    size_t off_nodes = align(off_mesh + live.size() * sizeof(DMesh));
+    size_t off_meshf = align(off_mesh + live.size() * sizeof(DMesh));
+    size_t off_fnodes = align(off_meshf + livef.size() * sizeof(DMeshF));
+    size_t off_ftris = align(off_fnodes + fnodes.size() * 4 + 32);
+    size_t off_nodes = align(off_ftris + ftris.size() * 4 + 48);
     size_t off_tris = align(off_nodes + nodes.size() * 4);
     size_t off_attr = align(off_tris + tris.size() * 4);
     size_t off_tex = align(off_attr + attrs.size() * sizeof(DTriAttr));
@@ -511,6 +523,9 @@ extern "C" int mi_scene_upload(mi_ctx* c, const mi_scene_desc* d) {
     put(off_list, list.data(), list.size() * sizeof(DObject));
     put(off_mat, mats.data(), mats.size() * sizeof(DMaterial));
     put(off_mesh, live.data(), live.size() * sizeof(DMesh));
+    put(off_meshf, livef.data(), livef.size() * sizeof(DMeshF));
+    put(off_fnodes, fnodes.data(), fnodes.size() * 4);
+    put(off_ftris, ftris.data(), ftris.size() * 4);
     put(off_nodes, nodes.data(), nodes.size() * 4);
     put(off_tris, tris.data(), tris.size() * 4);
     put(off_attr, attrs.data(), attrs.size() * sizeof(DTriAttr));
@@ -529,6 +544,10 @@ extern "C" int mi_scene_upload(mi_ctx* c, const mi_scene_desc* d) {
     c->S.n_list_tri = n_list[0]; c->S.n_list_sphere = n_list[1]; c->S.n_list_plane = n_list[2]; c->S.n_list_volume = n_list[3];
     c->S.materials = (const DMaterial*)(b + off_mat);
     c->S.meshes = (const DMesh*)(b + off_mesh);
+    c->S.meshf = (const DMeshF*)(b + off_meshf);
+    c->S.fnodes = (const float*)(b + off_fnodes);
+    c->S.ftris = (const float*)(b + off_ftris);
+    c->S.n_fnodes = (int)(fnodes.size() / 8);
     c->S.nodes = (const float*)(b + off_nodes);
     c->S.tris = (const float*)(b + off_tris);
     c->S.triattr = (const DTriAttr*)(b + off_attr);
@@ -612,16 +631,27 @@ static void make_camera(const mi_camera_desc* cam, DCamera* C) {
 // slot per path.  The batch is sized to the free HBM (288 GB on MI355X: the whole 1080p/256 spp
 // frame, 531 M paths = 112 GB, is ONE batch), halved on allocation failure.
 static const size_t kWfBytesPerPath = 2 * (size_t)kWfPlanes * sizeof(float4) + 4 + sizeof(float4);
+static const size_t kWfBytesPerPathTwoStage = (size_t)kCandMax * sizeof(uint2) + sizeof(uint2);     // candidates + header per queue slot
 
-static int wf_alloc(mi_ctx* c, WfArgs& a, uint32_t spp, uint64_t max_state_bytes, uint32_t& s_batch) {
+// which meshes this render walks two-stage (bit m = live mesh m)
+static uint32_t two_stage_mask(const mi_ctx* c, uint32_t flags) {
+    if (flags & MI_OPT_REFERENCE_WALK) return 0u;
+    uint32_t m = 0;
+    for (size_t i = 0; i < c->mesh_qualifies.size() && i < (size_t)kTwoStageMaxMeshes; i++)
+        if (c->mesh_qualifies[i] && ((flags & MI_OPT_TWO_STAGE) || c->mesh_default_ts[i])) m |= 1u << i;
+    return m;
+}
+
+static int wf_alloc(mi_ctx* c, WfArgs& a, uint32_t spp, uint64_t max_state_bytes, bool two_stage, uint32_t& s_batch) {
     uint64_t max_paths;
-    if (max_state_bytes != 0) max_paths = max_state_bytes / kWfBytesPerPath;        // the caller's budget (mi_render_opts)
+    const size_t per_path = kWfBytesPerPath + (two_stage ? kWfBytesPerPathTwoStage : 0);
+    if (max_state_bytes != 0) max_paths = max_state_bytes / per_path;        // the caller's budget (mi_render_opts)
     else {
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)8 << 30;
         // what this context already holds for the pipeline can be reused
-        free_b += c->wf_a_bytes + c->wf_b_bytes + c->wf_q_bytes + c->wf_samp_bytes;
-        max_paths = (uint64_t)((double)free_b * 0.6 / (double)kWfBytesPerPath);
+        free_b += c->wf_a_bytes + c->wf_b_bytes + c->wf_q_bytes + c->wf_samp_bytes + c->cand_bytes + c->cand_hdr_bytes;
+        max_paths = (uint64_t)((double)free_b * 0.6 / (double)per_path);
     }
     if (max_paths > (1ull << 31)) max_paths = 1ull << 31;           // 32-bit path indices
     uint64_t sb = max_paths / a.npix;
@@ -641,6 +671,8 @@ static int wf_alloc(mi_ctx* c, WfArgs& a, uint32_t spp, uint64_t max_state_bytes
         if (rc == MI_OK) rc = ensure(&c->d_wf_q, &c->wf_q_bytes, (size_t)a.cap * 4);
         if (rc == MI_OK) rc = ensure(&c->d_wf_samp, &c->wf_samp_bytes, (size_t)paths * sizeof(float4));
         if (rc == MI_OK) rc = ensure(&c->d_wf_acc, &c->wf_acc_bytes, (size_t)a.npix * sizeof(float4));
+        if (rc == MI_OK && two_stage) rc = ensure(&c->d_cand, &c->cand_bytes, (size_t)a.cap * kCandMax * sizeof(uint2));
+        if (rc == MI_OK && two_stage) rc = ensure(&c->d_cand_hdr, &c->cand_hdr_bytes, (size_t)a.cap * sizeof(uint2));
         if (rc == MI_OK) return MI_OK;
         if (rc != MI_ERR_OOM || sb == 1) return rc;
         (void)hipGetLastError();
@@ -649,13 +681,13 @@ static int wf_alloc(mi_ctx* c, WfArgs& a, uint32_t spp, uint64_t max_state_bytes
 }
 
 // sizes and allocates (host-side work: must happen BEFORE the timing start event is recorded)
-static int wf_prepare(mi_ctx* c, const mi_camera_desc* cam, uint32_t padded, uint64_t max_state_bytes, WfArgs& a, uint32_t& s_batch) {
+static int wf_prepare(mi_ctx* c, const mi_camera_desc* cam, uint32_t padded, uint64_t max_state_bytes, bool two_stage, WfArgs& a, uint32_t& s_batch) {
     memset(&a, 0, sizeof a);
     a.npix = padded * (uint32_t)kTilePixels;
     const uint32_t spp = cam->aa_sample_count;
     if (spp > 0xffffu) return fail(MI_ERR_UNSUPPORTED, "wavefront variant: aa_sample_count must be <= 65535");
     if (cam->path_depth > 0xffffu) return fail(MI_ERR_UNSUPPORTED, "wavefront variant: path_depth must be <= 65535");
-    return wf_alloc(c, a, spp, max_state_bytes, s_batch);
+    return wf_alloc(c, a, spp, max_state_bytes, two_stage, s_batch);
 }
 
 // Primary-ray culling for the wavefront pipeline.  For every 32x32 tile: which Triangle / Sphere entries of
@@ -862,26 +894,35 @@ static int render_tiles_wavefront(mi_ctx* c, const K1Args& k, const mi_camera_de
     a.diag = nullptr;           // developer builds (-DPT_WF_STAMPS): phase stamps of wf_main
     if (c->tune.wf_stamps) { a.diag = c->d_diag; HIP_TRY(hipMemsetAsync(c->d_diag, 0, 16 * sizeof(unsigned long long), stream)); }
     a.refill_min = c->tune.refill_min;
+    // Which meshes are walked how: the two-stage meshes (wf_trav_f + wf_replay), the rest through the reference's tree (wf_trav).
+    const uint32_t all_meshes = c->S.n_meshes >= 32 ? 0xffffffffu : ((1u << c->S.n_meshes) - 1u);
+    const uint32_t ts_mask = two_stage_mask(c, flags) & all_meshes;
+    const uint32_t ref_mask = all_meshes & ~ts_mask;
     // wf_trav LDS mode: 2 = BVH nodes in LDS, triangles through L1 (default when the nodes fit 64 KB:
     // teapot 15 KB -> 8 blocks per CU; 122.6 ms vs 126.0 ms for mode 1 on cfg2 1080p/256), 1 = nodes +
-    // triangles (what the megakernels stage), 0 = everything from global memory
-    const size_t node_bytes = (size_t)c->S.n_nodes * 32;
+    // triangles (what the megakernels stage), 0 = everything from global memory.  The LDS window is the head of the node
+    // pool up to the last tree wf_trav walks (the scene compiler places those trees first).
+    int ref_nodes = 0;
+    for (size_t m = 0; m < c->mesh_node_end.size() && m < 32; m++) if ((ref_mask >> m) & 1u) ref_nodes = std::max(ref_nodes, c->mesh_node_end[m]);
+    const size_t node_bytes = (size_t)ref_nodes * 32;
     // 3 = nodes in LDS too, but they need most of a CU's 160 KB: ONE 1024-thread block per CU (16 waves)
     int trav_lds_mode = 0;
-    if (c->S.n_meshes > 0 && !c->tune.global_bvh) trav_lds_mode = node_bytes <= 64u * 1024u ? 2 : (node_bytes <= 156u * 1024u ? 3 : 0);
+    if (ref_nodes > 0 && !c->tune.global_bvh) trav_lds_mode = node_bytes <= 64u * 1024u ? 2 : (node_bytes <= 156u * 1024u ? 3 : 0);
     if (c->tune.trav_lds >= 0) {
         const int m = c->tune.trav_lds;
-        if (m == 0 || (m == 1 && lds) || (m == 2 && node_bytes <= 64u * 1024u) || (m == 3 && node_bytes <= 156u * 1024u)) trav_lds_mode = m;
+        if (m == 0 || (m == 1 && lds && ref_nodes == c->S.n_nodes) || (m == 2 && node_bytes <= 64u * 1024u) || (m == 3 && node_bytes <= 156u * 1024u)) trav_lds_mode = m;
     }
     const size_t trav_lds_bytes = trav_lds_mode == 1 ? c->lds_bytes : (trav_lds_mode >= 2 ? node_bytes : 0);
-    a.R.lds_nodes = trav_lds_mode ? (uint32_t)c->S.n_nodes : 0;
+    a.R.lds_nodes = trav_lds_mode ? (uint32_t)ref_nodes : 0;
     a.R.lds_tris = trav_lds_mode == 1 ? (uint32_t)c->S.n_tris : 0;
+    a.cand = (uint2*)c->d_cand; a.cand_hdr = (uint2*)c->d_cand_hdr;
     float4* bufs[2] = { (float4*)c->d_wf_a, (float4*)c->d_wf_b };
     uint32_t trav_bpc = 6;                  // resident blocks per CU: bounded by LDS (160 KB) and by 8 waves/SIMD
     if (trav_lds_mode == 2) { trav_bpc = (uint32_t)((160u * 1024u) / (node_bytes ? node_bytes : 1)); if (trav_bpc > 8) trav_bpc = 8; if (trav_bpc < 2) trav_bpc = 2; }
     if (trav_lds_mode == 3) trav_bpc = 1;
     if (c->tune.trav_bpc > 0) trav_bpc = (uint32_t)c->tune.trav_bpc;
     const uint32_t trav_blocks = (uint32_t)c->n_cus * trav_bpc;
+    const uint32_t travf_blocks = (uint32_t)c->n_cus * 6u, replay_blocks = (uint32_t)c->n_cus * 8u;
 
     // per-kernel timing: one event pair per launch, summed after the frame
     size_t ev_used = 0;
@@ -890,7 +931,7 @@ static int render_tiles_wavefront(mi_ctx* c, const K1Args& k, const mi_camera_de
     // of a 1/8 share, so multi-rank renders skip it unless asked (MI_RT_WF_KERNEL_TIMING=0/1 overrides)
     bool per_kernel_timing = a.R.world == 1;
     if (c->tune.kernel_timing >= 0) per_kernel_timing = c->tune.kernel_timing != 0;
-    auto stamp = [&](int kind) -> int {      // kind: 0 wf_main, 1 wf_trav, 2 wf_reduce; call before AND after the launch
+    auto stamp = [&](int kind) -> int {      // kind: 0 wf_main, 1 wf_trav, 2 wf_reduce, 3 wf_trav_f, 4 wf_replay; call before AND after the launch
         if (!per_kernel_timing) return MI_OK;
         if (ev_used == c->wf_ev.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return MI_ERR_HIP; c->wf_ev.push_back(e); }
         if (hipEventRecord(c->wf_ev[ev_used++], stream) != hipSuccess) return MI_ERR_HIP;
@@ -918,8 +959,19 @@ static int render_tiles_wavefront(mi_ctx* c, const K1Args& k, const mi_camera_de
             // memory: the compute stream never waits for the host
             const uint32_t seq = ++c->hdr_seq;
             HIP_TRY(launch_wf_prefix(cnt, cnt + 2 * S_, d_in_count, d_in_pfx, d_trav_pfx, d_hdr, c->h_hdr_dev, seq, stream));
-            if (c->S.n_meshes > 0)       // persistent walkers; they leave at once when the queue is empty
+            // persistent walkers; they leave at once when the queue is empty.  Successive launches merge their meshes' hits
+            // into the hit record (strictly closer wins, ties go to the lower Scene.objects index: order-independent)
+            if (ref_mask) {
+                a.trav_mask = ref_mask;
                 WF_TIMED(1, launch_wf_trav(a, trav_blocks, trav_lds_mode, trav_lds_bytes, &c->big_lds_enabled, stream));
+            }
+            if (ts_mask) {
+                a.trav_mask = ts_mask;
+                // the walkers of the first launch have advanced the shared queue cursor: rewind it (stream order)
+                if (ref_mask) HIP_TRY(hipMemsetAsync(a.trav_head, 0, sizeof(uint32_t), stream));
+                WF_TIMED(3, launch_wf_trav_f(a, travf_blocks, stream));
+                WF_TIMED(4, launch_wf_replay(a, replay_blocks, stream));
+            }
             // wait for wf_prefix's header (written into pinned host memory) while wf_trav runs
             {
                 volatile uint32_t* hh = c->h_hdr;
@@ -950,10 +1002,11 @@ static int render_tiles_wavefront(mi_ctx* c, const K1Args& k, const mi_camera_de
 #undef WF_TIMED
     HIP_TRY(hipStreamSynchronize(stream));
     for (int k = 0; k < 8; k++) c->wf_counts[k] = counts[k];
-    c->wf_ms[0] = c->wf_ms[1] = c->wf_ms[2] = 0.0f; c->wf_ms[3] = (float)(ev_used / 2);
+    for (int k = 0; k < 8; k++) c->wf_ms[k] = 0.0f;
+    c->wf_ms[3] = (float)(ev_used / 2);
     for (size_t e = 0; e + 1 < ev_used; e += 2) {
         float ms = 0.0f;
-        if (hipEventElapsedTime(&ms, c->wf_ev[e], c->wf_ev[e + 1]) == hipSuccess) c->wf_ms[ev_kind[e]] += ms;
+        if (hipEventElapsedTime(&ms, c->wf_ev[e], c->wf_ev[e + 1]) == hipSuccess) c->wf_ms[ev_kind[e] < 3 ? ev_kind[e] : ev_kind[e] + 1] += ms;
     }
     return MI_OK;
 }
@@ -1008,7 +1061,7 @@ static int render_tiles(mi_ctx* c, const mi_camera_desc* cam, const mi_render_op
     }
     WfArgs wa; uint32_t wf_batch = 1;
     if (variant == MI_VARIANT_WAVEFRONT && !phong && !recursive) {
-        int rcp = wf_prepare(c, cam, padded, o->max_state_bytes, wa, wf_batch);
+        int rcp = wf_prepare(c, cam, padded, o->max_state_bytes, two_stage_mask(c, o->flags) != 0u, wa, wf_batch);
         if (rcp != MI_OK) return rcp;
     }
     HIP_TRY(hipEventRecord(c->ev_start, stream));
@@ -1098,12 +1151,12 @@ extern "C" int mi_reserve(mi_ctx* c, const mi_camera_desc* cam, int32_t world, u
     memset(&a, 0, sizeof a);
     a.npix = padded * (uint32_t)kTilePixels;
     uint32_t s_batch = 1;
-    return wf_alloc(c, a, cam->aa_sample_count, max_state_bytes, s_batch);
+    return wf_alloc(c, a, cam->aa_sample_count, max_state_bytes, two_stage_mask(c, 0u) != 0u, s_batch);
 }
 
-extern "C" int mi_last_pipeline_ms(mi_ctx* c, float* out4) {
-    if (!c || !out4) return fail(MI_ERR_INVALID, "mi_last_pipeline_ms: bad argument");
-    for (int i = 0; i < 4; i++) out4[i] = c->wf_ms[i];
+extern "C" int mi_last_pipeline_ms(mi_ctx* c, float* out8) {
+    if (!c || !out8) return fail(MI_ERR_INVALID, "mi_last_pipeline_ms: bad argument");
+    for (int i = 0; i < 8; i++) out8[i] = c->wf_ms[i];
     return MI_OK;
 }
 
@@ -1163,6 +1216,213 @@ extern "C" int mi_render(mi_ctx* c, const mi_camera_desc* cam, const mi_render_o
         float ms = 0.0f;
         HIP_TRY(hipEventElapsedTime(&ms, c->ev_start, c->ev_stop)); stats->kernel_ms = ms;
         HIP_TRY(hipEventElapsedTime(&ms, t0, t1)); stats->total_ms = ms;
+    }
+    return MI_OK;
+}
+
+// ------------------------------------------------------------------ multi-GPU behind the ABI
+// One process drives N devices: one mi_ctx, one stream and (per frame) one host thread per device, the image cut into
+// 32x32 tiles with tile t on device t mod N (the partition of dist.py), and exactly ONE exchange per frame: every peer
+// SENDS its compact tile buffer to device 0 over its own xGMI link (RCCL ncclSend / ncclRecv inside one group: a fan-in,
+// not a ring — xGMI is point-to-point, 7 links per GPU, so the 7 transfers of 3.1 MB run side by side), then K3 + K4 on
+// device 0.  RCCL is resolved at run time (dlopen), so single-GPU users of this library do not need it installed.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+namespace {
+struct Rccl {
+    void* so = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    bool load(std::string* why) {
+        if (so) return true;
+        const char* names[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
+        for (const char* n : names) { so = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (so) break; }
+        if (!so) { *why = std::string("cannot load RCCL: ") + (dlerror() ? dlerror() : "?"); return false; }
+#define RCCL_SYM(field, name) field = (decltype(field))dlsym(so, name); if (!field) { *why = std::string("RCCL lacks ") + name; return false; }
+        RCCL_SYM(CommInitAll, "ncclCommInitAll"); RCCL_SYM(CommDestroy, "ncclCommDestroy"); RCCL_SYM(GroupStart, "ncclGroupStart");
+        RCCL_SYM(GroupEnd, "ncclGroupEnd"); RCCL_SYM(Send, "ncclSend"); RCCL_SYM(Recv, "ncclRecv"); RCCL_SYM(GetErrorString, "ncclGetErrorString");
+#undef RCCL_SYM
+        return true;
+    }
+};
+Rccl g_rccl;
+}  // namespace
+
+struct mi_multi {
+    std::vector<int> devices;
+    std::vector<mi_ctx*> ctx;
+    std::vector<ncclComm_t> comm;
+    // device 0: gathered[world][tiles_padded][1024][3] (its own share is rendered straight into slice 0);
+    // every other device: its compact buffer.  Signatures likewise.
+    std::vector<void*> d_compact; std::vector<size_t> compact_bytes;
+    std::vector<void*> d_sig; std::vector<size_t> sig_bytes;
+    void* d_sig_image = nullptr; size_t sig_image_bytes = 0;
+};
+
+#define RCCL_TRY(expr)                                                                              \
+    do {                                                                                            \
+        ncclResult_t r_ = (expr);                                                                   \
+        if (r_ != ncclSuccess) return fail(MI_ERR_HIP, "%s failed: %s", #expr, g_rccl.GetErrorString(r_)); \
+    } while (0)
+
+extern "C" void mi_multi_destroy(mi_multi* m) {
+    if (!m) return;
+    for (size_t r = 0; r < m->ctx.size(); r++) {
+        if (!m->ctx[r]) continue;
+        (void)hipSetDevice(m->devices[r]);
+        (void)hipDeviceSynchronize();
+        if (r < m->comm.size() && m->comm[r]) (void)g_rccl.CommDestroy(m->comm[r]);
+        if (r < m->d_compact.size() && m->d_compact[r]) (void)hipFree(m->d_compact[r]);
+        if (r < m->d_sig.size() && m->d_sig[r]) (void)hipFree(m->d_sig[r]);
+        if (r == 0 && m->d_sig_image) (void)hipFree(m->d_sig_image);
+        mi_ctx_destroy(m->ctx[r]);
+    }
+    delete m;
+}
+
+extern "C" int mi_multi_create(int n_devices, const int* devices, mi_multi** out) {
+    if (!out) return fail(MI_ERR_INVALID, "mi_multi_create: out is NULL");
+    *out = nullptr;
+    if (n_devices < 1 || n_devices > 64) return fail(MI_ERR_INVALID, "mi_multi_create: n_devices %d out of range", n_devices);
+    mi_multi* m = new mi_multi();
+    for (int r = 0; r < n_devices; r++) {
+        m->devices.push_back(devices ? devices[r] : r);
+        for (int q = 0; q < r; q++) if (m->devices[(size_t)q] == m->devices[(size_t)r]) {
+            const int dup = m->devices[(size_t)r];
+            delete m;
+            return fail(MI_ERR_INVALID, "mi_multi_create: device %d listed twice", dup);
+        }
+    }
+    m->ctx.assign((size_t)n_devices, nullptr); m->comm.assign((size_t)n_devices, nullptr);
+    m->d_compact.assign((size_t)n_devices, nullptr); m->compact_bytes.assign((size_t)n_devices, 0);
+    m->d_sig.assign((size_t)n_devices, nullptr); m->sig_bytes.assign((size_t)n_devices, 0);
+    for (int r = 0; r < n_devices; r++) {
+        const int rc = mi_ctx_create(m->devices[(size_t)r], &m->ctx[(size_t)r]);
+        if (rc != MI_OK) { const std::string msg = g_err; mi_multi_destroy(m); g_err = msg; return rc; }
+    }
+    std::string why;
+    if (!g_rccl.load(&why)) { mi_multi_destroy(m); return fail(MI_ERR_UNSUPPORTED, "%s", why.c_str()); }
+    const ncclResult_t r = g_rccl.CommInitAll(m->comm.data(), n_devices, m->devices.data());
+    if (r != ncclSuccess) {
+        for (auto& cm : m->comm) cm = nullptr;
+        mi_multi_destroy(m);
+        return fail(MI_ERR_HIP, "ncclCommInitAll(%d devices) failed: %s", n_devices, g_rccl.GetErrorString(r));
+    }
+    *out = m;
+    return MI_OK;
+}
+
+extern "C" int mi_multi_device_count(const mi_multi* m) { return m ? (int)m->ctx.size() : 0; }
+
+// Run fn(rank) on one host thread per device; the first failure (code + message) is reported in the caller's thread.
+template <class F> static int on_every_device(mi_multi* m, F fn) {
+    const size_t n = m->ctx.size();
+    std::vector<int> rc(n, MI_OK); std::vector<std::string> msg(n);
+    auto body = [&](size_t r) { rc[r] = fn((int)r); if (rc[r] != MI_OK) msg[r] = g_err; };
+    std::vector<std::thread> th;
+    for (size_t r = 1; r < n; r++) th.emplace_back(body, r);
+    body(0);
+    for (auto& t : th) t.join();
+    for (size_t r = 0; r < n; r++) if (rc[r] != MI_OK) { g_err = "device " + std::to_string(m->devices[r]) + ": " + msg[r]; return rc[r]; }
+    return MI_OK;
+}
+
+extern "C" int mi_multi_scene_upload(mi_multi* m, const mi_scene_desc* scene) {
+    if (!m || !scene) return fail(MI_ERR_INVALID, "mi_multi_scene_upload: NULL argument");
+    // the scene is small (KBs .. a few hundred MB of textures) and 288 GB per GPU make replication free
+    return on_every_device(m, [&](int r) { return mi_scene_upload(m->ctx[(size_t)r], scene); });
+}
+
+extern "C" int mi_multi_reserve(mi_multi* m, const mi_camera_desc* cam, uint64_t max_state_bytes) {
+    if (!m) return fail(MI_ERR_INVALID, "mi_multi_reserve: NULL argument");
+    const int world = (int)m->ctx.size();
+    return on_every_device(m, [&](int r) { return mi_reserve(m->ctx[(size_t)r], cam, world, max_state_bytes); });
+}
+
+extern "C" int mi_multi_render(mi_multi* m, const mi_camera_desc* cam, const mi_render_opts* opts, float* out_rgb_f32,
+                               uint8_t* out_rgb_u8, uint32_t* out_sig, mi_stats* stats) {
+    if (!m || !opts) return fail(MI_ERR_INVALID, "mi_multi_render: NULL argument");
+    int rc = check_camera(cam);
+    if (rc != MI_OK) return rc;
+    const int world = (int)m->ctx.size();
+    uint32_t tx, ty, total, padded;
+    tile_counts(cam, world, &tx, &ty, &total, &padded);
+    const size_t slice_f = (size_t)padded * kTilePixels * 3, slice_s = (size_t)padded * kTilePixels;     // elements per rank
+    const size_t npix = (size_t)cam->screen_width * cam->screen_height;
+    const bool want_sig = opts->want_signature && out_sig;
+    const auto t_begin = std::chrono::steady_clock::now();
+    // buffers: device 0 holds the gathered array, the peers their own slice
+    for (int r = 0; r < world; r++) {
+        HIP_TRY(hipSetDevice(m->devices[(size_t)r]));
+        const size_t nf = (r == 0 ? (size_t)world : 1) * slice_f * sizeof(float), ns = (r == 0 ? (size_t)world : 1) * slice_s * 4;
+        if ((rc = ensure(&m->d_compact[(size_t)r], &m->compact_bytes[(size_t)r], nf)) != MI_OK) return rc;
+        if (want_sig && (rc = ensure(&m->d_sig[(size_t)r], &m->sig_bytes[(size_t)r], ns)) != MI_OK) return rc;
+    }
+    mi_ctx* c0 = m->ctx[0];
+    HIP_TRY(hipSetDevice(m->devices[0]));
+    if ((rc = ensure((void**)&c0->d_image, &c0->image_bytes, npix * 3 * sizeof(float))) != MI_OK) return rc;
+    if (out_rgb_u8 && (rc = ensure((void**)&c0->d_u8, &c0->u8_bytes, npix * 3)) != MI_OK) return rc;
+    if (want_sig && (rc = ensure(&m->d_sig_image, &m->sig_image_bytes, npix * 4)) != MI_OK) return rc;
+
+    // ---- every device renders its tiles (one host thread each; the wavefront pipeline drives its passes from the host) ----
+    std::vector<mi_stats> st((size_t)world);
+    rc = on_every_device(m, [&](int r) {
+        mi_ctx* c = m->ctx[(size_t)r];
+        if (hipSetDevice(c->device) != hipSuccess) return fail(MI_ERR_HIP, "hipSetDevice failed");
+        mi_render_opts o = *opts;
+        o.rank = r; o.world = world; o.want_signature = want_sig ? 1 : 0;
+        const int rr = render_tiles(c, cam, &o, (float*)m->d_compact[(size_t)r], want_sig ? (uint32_t*)m->d_sig[(size_t)r] : nullptr, c->stream, &st[(size_t)r]);
+        if (rr != MI_OK) return rr;
+        if (hipStreamSynchronize(c->stream) != hipSuccess) return fail(MI_ERR_HIP, "hipStreamSynchronize failed");
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, c->ev_start, c->ev_stop) == hipSuccess) st[(size_t)r].kernel_ms = ms;
+        return (int)MI_OK;
+    });
+    if (rc != MI_OK) return rc;
+
+    // ---- the frame's single exchange: fan-in of the compact buffers to device 0 (one group, issued from this thread) ----
+    if (world > 1) {
+        RCCL_TRY(g_rccl.GroupStart());
+        for (int r = 1; r < world; r++) {
+            RCCL_TRY(g_rccl.Recv((float*)m->d_compact[0] + (size_t)r * slice_f, slice_f, ncclFloat, r, m->comm[0], c0->stream));
+            RCCL_TRY(g_rccl.Send(m->d_compact[(size_t)r], slice_f, ncclFloat, 0, m->comm[(size_t)r], m->ctx[(size_t)r]->stream));
+            if (want_sig) {
+                RCCL_TRY(g_rccl.Recv((uint32_t*)m->d_sig[0] + (size_t)r * slice_s, slice_s, ncclUint32, r, m->comm[0], c0->stream));
+                RCCL_TRY(g_rccl.Send(m->d_sig[(size_t)r], slice_s, ncclUint32, 0, m->comm[(size_t)r], m->ctx[(size_t)r]->stream));
+            }
+        }
+        RCCL_TRY(g_rccl.GroupEnd());
+    }
+    // ---- K3 + K4 on device 0, in stream order behind the receives ----
+    HIP_TRY(hipSetDevice(m->devices[0]));
+    HIP_TRY(launch_unpermute((const float*)m->d_compact[0], c0->d_image, cam->screen_width, cam->screen_height, tx, (uint32_t)world, padded, c0->stream));
+    if (out_rgb_f32) HIP_TRY(hipMemcpyAsync(out_rgb_f32, c0->d_image, npix * 3 * sizeof(float), hipMemcpyDeviceToHost, c0->stream));
+    if (out_rgb_u8) {
+        HIP_TRY(launch_tonemap(c0->d_image, c0->d_u8, (uint32_t)npix, 1.0f / cam->gamma, c0->stream));
+        HIP_TRY(hipMemcpyAsync(out_rgb_u8, c0->d_u8, npix * 3, hipMemcpyDeviceToHost, c0->stream));
+    }
+    if (want_sig) {
+        HIP_TRY(launch_sig_unpermute((const uint32_t*)m->d_sig[0], (uint32_t*)m->d_sig_image, cam->screen_width, cam->screen_height, tx, (uint32_t)world, padded, c0->stream));
+        HIP_TRY(hipMemcpyAsync(out_sig, m->d_sig_image, npix * 4, hipMemcpyDeviceToHost, c0->stream));
+    }
+    for (int r = world - 1; r >= 0; r--) {          // the peers' sends, then device 0
+        HIP_TRY(hipSetDevice(m->devices[(size_t)r]));
+        HIP_TRY(hipStreamSynchronize(m->ctx[(size_t)r]->stream));
+    }
+    if (stats) {
+        memset(stats, 0, sizeof *stats);
+        for (int r = 0; r < world; r++) {
+            stats->samples += st[(size_t)r].samples; stats->pixels += st[(size_t)r].pixels; stats->tiles += st[(size_t)r].tiles;
+            stats->kernel_ms = std::max(stats->kernel_ms, st[(size_t)r].kernel_ms);             // the slowest device's pipeline pass
+        }
+        stats->tiles_padded = padded; stats->scene_bytes = st[0].scene_bytes; stats->scene_in_lds = st[0].scene_in_lds;
+        stats->total_ms = (float)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t_begin).count() * 1e-3f;
     }
     return MI_OK;
 }

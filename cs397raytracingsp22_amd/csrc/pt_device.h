@@ -89,6 +89,19 @@ struct alignas(16) DMesh {
 };
 static_assert(sizeof(DMesh) % 16 == 0, "DMesh must be 16-byte sized");
 
+// Two-stage traversal data of a StaticMesh (bvh_build.hpp FTree): where its F-tree lives and the constants of the
+// per-ray padding bound.  qualifies = 0: the bound never applies to this mesh (object-space scale makes the reference's
+// absolute 1e-4 determinant test void) and it is always walked through the reference's own tree.
+struct alignas(16) DMeshF {
+    int32_t fnode_begin, fnode_end;   // this mesh's F-nodes in the F-node pool
+    int32_t ftri_begin;               // first entry of this mesh in the F-ordered triangle pool
+    int32_t qualifies;
+    float   E2, L;                    // max |e1||e2|, longest stored edge
+    float   cx, cy, cz, R;            // bounding sphere of the vertices (object space)
+    float   pad[2];
+};
+static_assert(sizeof(DMeshF) == 48, "DMeshF must be 48 bytes");
+
 // per-triangle shading attributes, 20 floats = 5 float4
 struct alignas(16) DTriAttr {
     float na[3], nb[3], nc[3];   // corner normals          geometry.rs:350
@@ -113,11 +126,17 @@ struct DScene {
     // independent, ties go to the lower Scene.objects index (tracing.rs:335), and only
     // volumes draw random numbers, in their original relative order (geometry.rs:517).
     const PT_CONST_AS DObject*   list;
+    // two-stage traversal (meshes that qualify): F-tree nodes (same 2 x float4 node format; leaf word = (first << 3) | (count - 1)
+    // into ftris), the F-ordered triangles {a.xyz, tri index}{e1.xyz, 0}{e2.xyz, 0}, and the per-mesh constants
+    const PT_CONST_AS float*     fnodes;
+    const PT_CONST_AS float*     ftris;
+    const PT_CONST_AS DMeshF*    meshf;
     int32_t n_list_tri, n_list_sphere, n_list_plane, n_list_volume;
     int32_t n_objects;
     int32_t n_meshes;
     int32_t n_nodes;
     int32_t n_tris;
+    int32_t n_fnodes;
 };
 
 // Camera::generate_rays constants (tracing.rs:160-163,187-191), computed once on the
@@ -182,6 +201,8 @@ constexpr int kWfPlanes = 6;
 // atomics (one word saturates at ~88 atomics/us on gfx950).  A shard's region can never
 // overflow: it receives at most the paths its own input blocks hold.
 constexpr int kWfShards = 256;
+constexpr int kCandMax = 8;          // two-stage: candidate slots per queued ray (more passing triangles -> reference walk for that mesh)
+constexpr int kTwoStageMaxMeshes = 24;   // mesh index bits in cand_hdr
 struct WfArgs {
     DScene  S;
     DCamera C;
@@ -219,6 +240,13 @@ struct WfArgs {
     // tile_mask[tiles_total + tile]: low 32 bits = the same for the meshes' root boxes, bit 63 = nothing
     // at all is reachable from this tile.
     const PT_CONST_AS unsigned long long* tile_mask;
+    // mesh walks: bit m of trav_mask = mesh m is walked by THIS launch (wf_trav: the meshes walked through the reference's
+    // tree; wf_trav_f / wf_replay: the two-stage meshes).  Results of successive launches merge through the hit record.
+    uint32_t trav_mask;
+    // two-stage: candidates of queue entry vi = cand[vi * kCandMax .. ) as {t, (mesh << 24) | triangle}; cand_hdr[vi] =
+    // {position of the path in st_out, count | bit (8 + m): mesh m must take the reference walk (overflow, bound not applicable)}
+    uint2* cand;
+    uint2* cand_hdr;
     unsigned long long* diag;   // developer builds with -DPT_WF_STAMPS: [16] summed s_memtime deltas of sampled wf_main waves
 };
 

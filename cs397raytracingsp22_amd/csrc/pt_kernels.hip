@@ -1501,8 +1501,6 @@ __global__ __launch_bounds__(kBlock, PT_MAIN_WAVES) void wf_main(WfArgs A) {
         { Hit2 hw; hw.t = best.t; hw.obj = best.obj; *st_hit(A.st_out, pos, cap) = hw; }
         if (!cls_a) *st_tri(A.st_out, pos, cap) = best.tri;
         if (SIG) *st_sig(A.st_out, pos, cap) = P.sig;
-        // plane 5: which mesh the walk starts with — only worth 32 bytes of traffic when there is more than one
-        if (enters && S.n_meshes > 1) A.st_out[st_idx(5, pos, cap)] = make_float4(0.0f, 0.0f, __int_as_float(tm), 0.0f);
     }
     if (alive && enters) A.trav_q[(size_t)out_shard * A.region + qpos] = (uint32_t)pos;
 #ifdef PT_WF_STAMPS
@@ -1593,13 +1591,14 @@ __global__ __launch_bounds__(BS, (BS == 256 ? PT_TRAV_WAVES : 4)) void wf_trav(W
                 const Hit2 hr = *st_hit(A.st_out, pos, cap);
                 o = mk3(q0.x, q0.y, q0.z); d = mk3(q0.w, q1.x, q1.y);
                 best.t = hr.t; best.obj = hr.obj; best.tri = -1; best.u = 0.0f; best.v = 0.0f;
-                tm = 0;                                  // one mesh: the ray entered it
-                if (S.n_meshes > 1) tm = __float_as_int(A.st_out[st_idx(5, pos, cap)].z);
-                // the root test of mesh tm passed in wf_main; redo the set-up (same arithmetic)
-                (void)enter_next_mesh(S, B, tm, o, d, t_min, t_max, too, tod, tinv, ti, tend, ttb);
-                tbt = t_max; tbtri = -1; tbu = tbv = 0.0f;
-                B.node(ti, c0, c1);
-                have = true;
+                // the ray entered SOME mesh's root box in wf_main; find the first one of THIS launch's meshes it enters
+                // (same root tests, same arithmetic; a ray that enters none of them has nothing to do here)
+                tm = 0;
+                if (enter_next_mesh(S, B, tm, o, d, t_min, t_max, too, tod, tinv, ti, tend, ttb, A.trav_mask)) {
+                    tbt = t_max; tbtri = -1; tbu = tbv = 0.0f;
+                    B.node(ti, c0, c1);
+                    have = true;
+                }
             }
             wnext += min(avail, n_idle);
         }
@@ -1637,7 +1636,7 @@ __global__ __launch_bounds__(BS, (BS == 256 ? PT_TRAV_WAVES : 4)) void wf_trav(W
         if (have && ti >= tend) {
             if (tbtri >= 0) consider(best, tbt, S.meshes[tm].object_index, tbtri, tbu, tbv);
             tm++;
-            if (enter_next_mesh(S, B, tm, o, d, t_min, t_max, too, tod, tinv, ti, tend, ttb)) {
+            if (enter_next_mesh(S, B, tm, o, d, t_min, t_max, too, tod, tinv, ti, tend, ttb, A.trav_mask)) {
                 tbt = t_max; tbtri = -1; tbu = tbv = 0.0f;
                 B.node(ti, c0, c1);
             } else {
@@ -1651,6 +1650,309 @@ __global__ __launch_bounds__(BS, (BS == 256 ? PT_TRAV_WAVES : 4)) void wf_trav(W
                 }
                 have = false;
             }
+        }
+    }
+}
+
+// ---------------------------------------------------------------- exact two-stage mesh traversal
+// For meshes whose file order makes the reference's index-range tree useless (obj/sphere.obj: 3800 box tests and 960
+// triangle tests per entering ray).  bvh_build.hpp states the argument; in short:
+//   pass 1 (wf_trav_f)  walks a spatial SAH tree over the triangles with boxes padded, per ray, by a proven bound on what the
+//                       reference's f32 Moller-Trumbore test can accept, and runs THAT test (tri_t, same operations) on the
+//                       leaves it reaches: every triangle the reference's test would pass becomes a candidate {t, index};
+//   pass 2 (wf_replay)  replays BVHNode::intersect_ray (geometry.rs:94-119) over the root-to-candidate paths only, in index
+//                       order with the reference's running bound: box rejections (flat boxes included), `t <= best`
+//                       acceptance and the later-equal-hit-wins rule are evaluated by the reference's own arithmetic on
+//                       the reference's own boxes.  Triangles that are no candidates fail the reference's test wherever the
+//                       reference reaches them and cannot change its result.
+// A ray the bound does not cover (B > 1/2, non-finite) or with more than kCandMax candidates in one mesh takes the plain
+// reference walk for that mesh inside wf_replay.
+
+// bvh_build.hpp two_stage_pad, same f32 expression
+__device__ __forceinline__ bool two_stage_pad(const PT_CONST_AS DMeshF* F, f3 o, f3 d, float t_max, float& rho_out, float& dt_out) {
+    const float eps = 5.9604645e-08f;
+    const float dn = sqrtf((d.x * d.x + d.y * d.y) + d.z * d.z) * 1.000001f;
+    const float ox = o.x - F->cx, oy = o.y - F->cy, oz = o.z - F->cz;
+    const float Sr = (sqrtf((ox * ox + oy * oy) + oz * oz) + F->R) * 1.000001f;
+    const float E2 = F->E2, L = F->L;
+    const float B = 7.0f * eps * E2 * dn * 1.0e4f;
+    const float rho = 2.0f * eps * dn * E2 * (16.0f * Sr + 14.0f * L) * 1.0e4f + 11.0f * eps * L;
+    const float dt = 2.0f * (8.1f * eps * E2 * Sr * 1.0e4f + fabsf(t_max) * (B + 2.001f * eps));
+    rho_out = 4.0f * rho + 16.0f * eps * Sr;
+    dt_out = 2.0f * dt;
+    return (B <= 0.5f) && (Sr <= 1.0e12f) && (rho_out <= 1.0e30f) && (dt_out <= 1.0e30f);
+}
+
+// AABB test of pass 1: the box grown by rho (bmin against o + rho, bmax against o - rho), parameter range [t_lo, t_hi]
+__device__ __forceinline__ bool slab_padded(f3 bmin, f3 bmax, f3 op, f3 om, f3 inv_d, float t_lo, float t_hi) {
+    float tmin = t_lo, tmax = t_hi;
+    {
+        float t0 = (bmin.x - op.x) * inv_d.x, t1 = (bmax.x - om.x) * inv_d.x;
+        bool sw = inv_d.x < 0.0f;
+        float ta = sw ? t1 : t0, tb = sw ? t0 : t1;
+        tmin = fmaxf(ta, tmin); tmax = fminf(tb, tmax);
+    }
+    {
+        float t0 = (bmin.y - op.y) * inv_d.y, t1 = (bmax.y - om.y) * inv_d.y;
+        bool sw = inv_d.y < 0.0f;
+        float ta = sw ? t1 : t0, tb = sw ? t0 : t1;
+        tmin = fmaxf(ta, tmin); tmax = fminf(tb, tmax);
+    }
+    {
+        float t0 = (bmin.z - op.z) * inv_d.z, t1 = (bmax.z - om.z) * inv_d.z;
+        bool sw = inv_d.z < 0.0f;
+        float ta = sw ? t1 : t0, tb = sw ? t0 : t1;
+        tmin = fmaxf(ta, tmin); tmax = fminf(tb, tmax);
+    }
+    return !(tmax <= tmin);
+}
+
+// next two-stage mesh (index >= m, bit set in `mask`) whose REFERENCE root box the ray enters (geometry.rs:103 at the root:
+// nothing below can be reached otherwise); sets up the object-space ray and the padded walk.  `fallback` receives the bits
+// of entered meshes the bound does not cover for this ray.
+__device__ __forceinline__ bool enter_next_mesh_f(const DScene& S, int& m, uint32_t mask, f3 o, f3 d, float t_min, float t_max,
+                                                  f3& oo, f3& od, f3& inv_d, f3& op, f3& om, float& t_lo, float& t_hi,
+                                                  int& fi, int& fend, int& ftb, uint32_t& fallback) {
+    cf4_ptr gn = (cf4_ptr)S.nodes;
+    for (; m < S.n_meshes && m < kTwoStageMaxMeshes; m++) {
+        if (!((mask >> m) & 1u)) continue;
+        auto M = &S.meshes[m];
+        oo = xform_point(M->inv_transform, o);                           // geometry.rs:304
+        od = xform_vector(M->inv_transform, d);
+        inv_d = mk3(1.0f / od.x, 1.0f / od.y, 1.0f / od.z);              // geometry.rs:57
+        const float4 n0 = gn[2 * M->node_begin], n1 = gn[2 * M->node_begin + 1];
+        if (__float_as_int(n1.w) < 0 &&                                   // a root that is a leaf is never box-tested (:95)
+            !slab(mk3(n0.x, n0.y, n0.z), mk3(n1.x, n1.y, n1.z), oo, inv_d, t_min, t_max)) continue;
+        auto F = &S.meshf[m];
+        float rho, dt;
+        if (!two_stage_pad(F, oo, od, t_max, rho, dt)) { fallback |= 1u << m; continue; }
+        op = mk3(oo.x + rho, oo.y + rho, oo.z + rho); om = mk3(oo.x - rho, oo.y - rho, oo.z - rho);
+        t_lo = t_min - dt; t_hi = t_max + dt;
+        fi = F->fnode_begin; fend = F->fnode_end; ftb = F->ftri_begin;
+        return true;
+    }
+    return false;
+}
+
+// pass 1: persistent walkers over the traversal queue (work distribution and refill exactly as wf_trav)
+__global__ __launch_bounds__(256, PT_TRAV_WAVES) void wf_trav_f(WfArgs A) {
+    const DScene& S = A.S;
+    const uint32_t n_q = A.hdr[2];
+    const uint32_t n_waves = gridDim.x * 4u;
+    const uint32_t chunk = 256u;
+    const bool shared_part = n_waves * chunk < n_q;
+    if (blockIdx.x * 4u * chunk >= n_q) return;
+    cf4_ptr FN = (cf4_ptr)S.fnodes;
+    cf4_ptr FT = (cf4_ptr)S.ftris;
+    const float t_min = 0.001f, t_max = A.C.max_trace_dist;
+    const uint32_t cap = A.cap;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave_id = blockIdx.x * 4u + (threadIdx.x >> 6);
+    uint32_t wnext = wave_id * chunk, wend = min(wnext + chunk, n_q);
+    bool drained = false;
+    if (wnext >= n_q) { wnext = wend = 0; drained = true; }
+
+    bool have = false, atleaf = false;
+    uint32_t vi = 0, pos = 0, nc = 0, fb = 0;
+    f3 too = mk3(0.0f, 0.0f, 0.0f), tod = too, tinv = too, op = too, om = too;
+    float t_lo = 0.0f, t_hi = 0.0f;
+    int tm = 0, fi = 0, fend = 0, ftb = 0;
+    float4 c0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), c1 = c0;
+    const int last_fnode = S.n_fnodes - 1;          // clamp for the load that follows the last node of a tree
+
+    while (true) {
+        // ---- refill idle lanes ----
+        unsigned long long need = __builtin_amdgcn_ballot_w64(!have);
+        const uint32_t n_idle = (uint32_t)__popcll(need);
+        if ((n_idle >= A.refill_min || n_idle == 64u) && !drained) {
+            if (wnext == wend) {
+                uint32_t base = n_q;
+                if (shared_part) {
+                    if (lane == 0) base = n_waves * chunk + atomicAdd(&A.trav_head[0], chunk);
+                    base = (uint32_t)__shfl((int)base, 0);
+                }
+                if (base >= n_q) drained = true;
+                else { wnext = base; wend = min(base + chunk, n_q); }
+            }
+            const uint32_t avail = wend - wnext;
+            const uint32_t rank = (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
+            const bool take = !have && rank < avail;
+            if (take) {
+                vi = wnext + rank;
+                uint32_t lo = 0, hi = (uint32_t)kWfShards;
+                while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (A.trav_pfx[mid] <= vi) lo = mid; else hi = mid; }
+                pos = A.trav_q[(size_t)lo * A.region + (vi - A.trav_pfx[lo])];
+                const float4 q0 = A.st_out[st_idx(0, pos, cap)], q1 = A.st_out[st_idx(1, pos, cap)];
+                const f3 o = mk3(q0.x, q0.y, q0.z), d = mk3(q0.w, q1.x, q1.y);
+                nc = 0; fb = 0; tm = 0; atleaf = false;
+                if (enter_next_mesh_f(S, tm, A.trav_mask, o, d, t_min, t_max, too, tod, tinv, op, om, t_lo, t_hi, fi, fend, ftb, fb)) {
+                    c0 = FN[2 * fi]; c1 = FN[2 * fi + 1];
+                    have = true;
+                } else {
+                    A.cand_hdr[vi] = make_uint2(pos, fb << 8);          // entered none of these meshes (or only uncovered ones)
+                }
+            }
+            wnext += min(avail, n_idle);
+        }
+        if (__builtin_amdgcn_ballot_w64(have) == 0ull) {
+            if (drained) break;
+            continue;
+        }
+
+        // ---- one voted step: a burst of F-node box tests, or the triangle tests of the leaves reached ----
+        const bool walking = have & !atleaf;
+        const int n_leaf = __popcll(__builtin_amdgcn_ballot_w64(have & atleaf));
+        const int n_walk = __popcll(__builtin_amdgcn_ballot_w64(walking));
+        if (n_walk >= n_leaf) {
+#pragma unroll
+            for (int j = 0; j < PT_TRAV_BURST; j++) {
+                const bool act = have & !atleaf & (fi < fend);
+                const bool hit = slab_padded(mk3(c0.x, c0.y, c0.z), mk3(c1.x, c1.y, c1.z), op, om, tinv, t_lo, t_hi);
+                const bool leaf = __float_as_int(c1.w) >= 0;
+                const bool stop = act & hit & leaf;                      // reached a leaf: its triangles are tested in a leaf step
+                const int nxt = hit ? fi + 1 : __float_as_int(c0.w);
+                atleaf = atleaf | stop;
+                const bool move = act & !stop;
+                fi = move ? nxt : fi;
+                if (move) { const int k = min(fi, last_fnode); c0 = FN[2 * k]; c1 = FN[2 * k + 1]; }
+            }
+        } else if (have & atleaf) {
+            const int payload = __float_as_int(c1.w);
+            const int first = ftb + (payload >> 3), count = (payload & 7) + 1;
+            for (int k = 0; k < count; k++) {
+                const float4 t0 = FT[3 * (first + k)], t1 = FT[3 * (first + k) + 1], t2 = FT[3 * (first + k) + 2];
+                float t, u, v;
+                const bool ok = tri_t(too, tod, mk3(t0.x, t0.y, t0.z), mk3(t1.x, t1.y, t1.z), mk3(t2.x, t2.y, t2.z), t_min, t_max, t, u, v);
+                if (ok) {
+                    if (nc < (uint32_t)kCandMax) { A.cand[(size_t)vi * kCandMax + nc] = make_uint2(__float_as_uint(t), ((uint32_t)tm << 24) | (uint32_t)__float_as_int(t0.w)); nc++; }
+                    else fb |= 1u << tm;                                  // too many passing triangles: reference walk for this mesh
+                }
+            }
+            atleaf = false;
+            fi = fi + 1;                                                  // a leaf's successor in pre-order
+            { const int k = min(fi, last_fnode); c0 = FN[2 * k]; c1 = FN[2 * k + 1]; }
+        }
+        if (have && !atleaf && fi >= fend) {
+            tm++;
+            const float4 q0 = A.st_out[st_idx(0, pos, cap)], q1 = A.st_out[st_idx(1, pos, cap)];
+            const f3 o = mk3(q0.x, q0.y, q0.z), d = mk3(q0.w, q1.x, q1.y);
+            if (enter_next_mesh_f(S, tm, A.trav_mask, o, d, t_min, t_max, too, tod, tinv, op, om, t_lo, t_hi, fi, fend, ftb, fb)) {
+                c0 = FN[2 * fi]; c1 = FN[2 * fi + 1];
+            } else {
+                A.cand_hdr[vi] = make_uint2(pos, nc | (fb << 8));
+                have = false;
+            }
+        }
+    }
+}
+
+// pass 2: one thread per queued ray
+__global__ __launch_bounds__(256) void wf_replay(WfArgs A) {
+    const DScene& S = A.S;
+    const uint32_t n_q = A.hdr[2];
+    const float t_min = 0.001f, t_max = A.C.max_trace_dist;
+    const uint32_t cap = A.cap;
+    cf4_ptr RN = (cf4_ptr)S.nodes;
+    Bvh<false> B;
+    bvh_bind(B, S, 0);
+    for (uint32_t vi = blockIdx.x * blockDim.x + threadIdx.x; vi < n_q; vi += gridDim.x * blockDim.x) {
+        const uint2 hdr = A.cand_hdr[vi];
+        const uint32_t nc = hdr.y & 0xffu, fb = hdr.y >> 8;
+        if (nc == 0u && fb == 0u) continue;
+        const size_t pos = hdr.x;
+        const float4 q0 = A.st_out[st_idx(0, pos, cap)], q1 = A.st_out[st_idx(1, pos, cap)];
+        const f3 o = mk3(q0.x, q0.y, q0.z), d = mk3(q0.w, q1.x, q1.y);
+        const Hit2 hr = *st_hit(A.st_out, pos, cap);
+        Best best; best.t = hr.t; best.obj = hr.obj; best.tri = -1; best.u = best.v = 0.0f;
+        int best_mesh = -1;
+        // candidates into registers (unused slots get the largest key)
+        uint32_t key[kCandMax]; float ct[kCandMax];
+#pragma unroll
+        for (int k = 0; k < kCandMax; k++) {
+            uint2 c = make_uint2(0u, 0xffffffffu);
+            if ((uint32_t)k < nc) c = A.cand[(size_t)vi * kCandMax + k];
+            ct[k] = __uint_as_float(c.x); key[k] = c.y;
+        }
+        long long last = -1;
+        int cur = -1, n_tris = 0, node_begin = 0;
+        f3 oo = o, od = d, inv = d;
+        float wt = t_max; int win = -1;
+        int prev = -1, fail_depth = 0x7fffffff;
+        for (uint32_t round = 0; round < nc; round++) {
+            // next candidate in (mesh, triangle index) order
+            uint32_t kmin = 0xffffffffu; float tsel = 0.0f;
+#pragma unroll
+            for (int k = 0; k < kCandMax; k++) {
+                const bool better = ((long long)key[k] > last) && (key[k] < kmin);
+                kmin = better ? key[k] : kmin; tsel = better ? ct[k] : tsel;
+            }
+            if (kmin == 0xffffffffu) break;
+            last = (long long)kmin;
+            const int m = (int)(kmin >> 24), tri = (int)(kmin & 0xffffffu);
+            if ((fb >> m) & 1u) continue;                                 // this mesh takes the reference walk below
+            if (m != cur) {
+                if (cur >= 0 && win >= 0) {
+                    const Best before = best;
+                    consider(best, wt, S.meshes[cur].object_index, win, 0.0f, 0.0f);
+                    if (best.tri != before.tri || best.obj != before.obj || best.t != before.t) best_mesh = cur;
+                }
+                cur = m;
+                auto M = &S.meshes[m];
+                oo = xform_point(M->inv_transform, o); od = xform_vector(M->inv_transform, d);
+                inv = mk3(1.0f / od.x, 1.0f / od.y, 1.0f / od.z);
+                n_tris = M->n_tris; node_begin = M->node_begin;
+                wt = t_max; win = -1; prev = -1; fail_depth = 0x7fffffff;
+            }
+            // BVHNode::intersect_ray restricted to the path root -> leaf `tri`; ancestors shared with the previous candidate
+            // were decided when it was walked (the reference tests a node once, with the bound it held then)
+            int s = 0, e = n_tris, me = 0, depth = 0, new_fail = 0x7fffffff;
+            bool dead = false;
+            while (e - s > 1) {
+                const bool shared = (prev >= s) & (prev < e);
+                if (shared) {
+                    if (depth == fail_depth) { dead = true; new_fail = fail_depth; break; }
+                } else {
+                    const float4 n0 = RN[2 * (node_begin + me)], n1 = RN[2 * (node_begin + me) + 1];
+                    if (!slab(mk3(n0.x, n0.y, n0.z), mk3(n1.x, n1.y, n1.z), oo, inv, t_min, wt)) { dead = true; new_fail = depth; break; }   // :103
+                }
+                const int mid = s + (e - s) / 2;                          // geometry.rs:209
+                if (tri < mid) { me = me + 1; e = mid; } else { me = me + 2 * (mid - s); s = mid; }
+                depth++;
+            }
+            fail_depth = dead ? new_fail : 0x7fffffff;
+            prev = tri;
+            if (!dead && tsel <= wt) { wt = tsel; win = tri; }            // :349 rejects only t > t_max: a later equal hit replaces
+        }
+        if (cur >= 0 && win >= 0) {
+            const Best before = best;
+            consider(best, wt, S.meshes[cur].object_index, win, 0.0f, 0.0f);
+            if (best.tri != before.tri || best.obj != before.obj || best.t != before.t) best_mesh = cur;
+        }
+        // meshes the bound did not cover for this ray, or with more passing triangles than candidate slots: the plain walk
+        for (int m = 0; m < S.n_meshes && m < kTwoStageMaxMeshes; m++) {
+            if (!((fb >> m) & 1u)) continue;
+            auto M = &S.meshes[m];
+            const f3 po = xform_point(M->inv_transform, o), pd = xform_vector(M->inv_transform, d);
+            float bt, bu, bv; int btri;
+            traverse_mesh(B, M->node_begin, M->node_end, M->tri_begin, po, pd, t_min, t_max, bt, btri, bu, bv);
+            if (btri >= 0) {
+                const Best before = best;
+                consider(best, bt, M->object_index, btri, bu, bv);
+                if (best.tri != before.tri || best.obj != before.obj || best.t != before.t) best_mesh = m;
+            }
+        }
+        if (best.tri >= 0) {
+            // the winner's barycentrics: the reference's test once more on that triangle (same operations, same bits)
+            auto M = &S.meshes[best_mesh];
+            const f3 po = xform_point(M->inv_transform, o), pd = xform_vector(M->inv_transform, d);
+            f3 a, e1, e2;
+            B.tri(M->tri_begin + best.tri, a, e1, e2);
+            float t, u, v;
+            (void)tri_t(po, pd, a, e1, e2, t_min, t_max, t, u, v);
+            Hit2 hw; hw.t = best.t; hw.obj = best.obj;
+            *st_hit(A.st_out, pos, cap) = hw;
+            *st_tri(A.st_out, pos, cap) = best.tri;
+            A.st_out[st_idx(5, pos, cap)] = make_float4(u, v, 0.0f, 0.0f);
         }
     }
 }
@@ -1833,6 +2135,14 @@ hipError_t launch_wf_trav(const WfArgs& a, uint32_t n_blocks, int lds_mode, size
     else if (lds_mode == 1) hipLaunchKernelGGL((wf_trav<1, 256>), grid, block, lds_bytes, stream, a);
     else if (lds_mode == 2) hipLaunchKernelGGL((wf_trav<2, 256>), grid, block, lds_bytes, stream, a);
     else hipLaunchKernelGGL((wf_trav<0, 256>), grid, block, 0, stream, a);
+    return hipGetLastError();
+}
+hipError_t launch_wf_trav_f(const WfArgs& a, uint32_t n_blocks, hipStream_t stream) {
+    hipLaunchKernelGGL(wf_trav_f, dim3(n_blocks), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+hipError_t launch_wf_replay(const WfArgs& a, uint32_t n_blocks, hipStream_t stream) {
+    hipLaunchKernelGGL(wf_replay, dim3(n_blocks), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 hipError_t launch_wf_prefix(uint32_t* out_count, uint32_t* trav_count, uint32_t* in_count, uint32_t* in_blkpfx,

@@ -143,9 +143,10 @@ class Context:
 
     def last_pipeline_ms(self):
         """Wavefront pipeline of the last render: dict of per-kernel duration sums (ms) and launch count."""
-        out = (C.c_float * 4)()
+        out = (C.c_float * 8)()
         abi.check(self._lib.mi_last_pipeline_ms(self._h, out))
-        return {"wf_main_ms": float(out[0]), "wf_trav_ms": float(out[1]), "wf_reduce_ms": float(out[2]), "launches": int(out[3])}
+        return {"wf_main_ms": float(out[0]), "wf_trav_ms": float(out[1]), "wf_reduce_ms": float(out[2]), "launches": int(out[3]),
+                "wf_trav_f_ms": float(out[4]), "wf_replay_ms": float(out[5])}
 
     def last_pipeline_counts(self):
         """Path counts of the last wavefront render (mi_last_pipeline_counts), for traffic accounting."""
@@ -166,6 +167,54 @@ class Context:
         ms = C.c_float()
         abi.check(self._lib.mi_last_kernel_ms(self._h, C.byref(ms)))
         return float(ms.value)
+
+
+class MultiContext:
+    """mi_multi: N GPUs of one node behind ONE handle (one context, stream and host thread per device inside the
+    library; tiles t % N; a single RCCL send/recv fan-in per frame; un-permute and tone-map on device 0)."""
+
+    def __init__(self, n_devices: int, devices=None):
+        self._lib = abi.load()
+        self._h = C.c_void_p()
+        arr = (C.c_int * n_devices)(*devices) if devices is not None else None
+        abi.check(self._lib.mi_multi_create(n_devices, arr, C.byref(self._h)))
+        self.n_devices = n_devices
+
+    def close(self):
+        if self._h:
+            self._lib.mi_multi_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload(self, flat: FlatScene):
+        abi.check(self._lib.mi_multi_scene_upload(self._h, C.byref(flat.desc)))
+
+    def reserve(self, cam: Camera, max_state_bytes: int = 0):
+        pod = cam.to_pod()
+        abi.check(self._lib.mi_multi_reserve(self._h, C.byref(pod), max_state_bytes))
+
+    def render(self, cam: Camera, seed: int = 1, want_f32=True, want_u8=True, want_sig=False, flags: int = 0,
+               max_state_bytes: int = 0):
+        """mi_multi_render: the whole image, assembled on device 0.  Same return value as Context.render."""
+        pod = cam.to_pod()
+        opts = abi.mi_render_opts(seed=seed, rank=0, world=1, variant=abi.MI_VARIANT_DEFAULT, want_signature=int(want_sig),
+                                  flags=flags, max_state_bytes=max_state_bytes)
+        H, W = cam.screen_height, cam.screen_width
+        f32 = np.empty((H, W, 3), np.float32) if want_f32 else None
+        u8 = np.empty((H, W, 3), np.uint8) if want_u8 else None
+        sig = np.empty((H, W), np.uint32) if want_sig else None
+        st = abi.mi_stats()
+        abi.check(self._lib.mi_multi_render(
+            self._h, C.byref(pod), C.byref(opts),
+            f32.ctypes.data if f32 is not None else None,
+            u8.ctypes.data if u8 is not None else None,
+            sig.ctypes.data if sig is not None else None, C.byref(st)))
+        return f32, u8, sig, st
 
 
 def compact_size(cam: Camera, world: int):

@@ -272,9 +272,10 @@ int  mi_last_kernel_ms(mi_ctx* ctx, float* ms);
  * mi_render_opts (0 = 60 % of the free HBM).  Optional. */
 int  mi_reserve(mi_ctx* ctx, const mi_camera_desc* cam, int32_t world, uint64_t max_state_bytes);
 
-/* Wavefront pipeline (MI_VARIANT_WAVEFRONT) of the most recent render: out4 = { sum of wf_main
- * launch durations, of wf_trav, of wf_reduce (ms, HIP events around every launch), launches }. */
-int  mi_last_pipeline_ms(mi_ctx* ctx, float* out4);
+/* Wavefront pipeline (MI_VARIANT_WAVEFRONT) of the most recent render: out8 = { sum of wf_main
+ * launch durations, of wf_trav, of wf_reduce (ms, HIP events around every launch), launches, sum of wf_trav_f, of
+ * wf_replay (the two-stage mesh traversal), 0, 0 }. */
+int  mi_last_pipeline_ms(mi_ctx* ctx, float* out8);
 
 /* Path counts of the most recent wavefront render, for traffic accounting: out8 = { passes (wf_main launches
  * that left survivors or ended the batch), class-A paths written to (and read back from) the HBM path state summed
@@ -288,6 +289,22 @@ int  mi_last_pipeline_counts(mi_ctx* ctx, uint64_t* out8);
  *           shade / regenerate / list sections, slab tests inside trees, path segments, 0 }.
  * active-lane fraction of a phase = lanes / (64 * trips). */
 int  mi_last_diag(mi_ctx* ctx, uint64_t* out16);
+
+/* ---- multi-GPU behind the ABI: replaces rayon's row split (tracing.rs:228) with N devices of one node ----
+ * One mi_multi owns one context, stream and (per frame) one host thread per device.  The image is cut into MI_TILE^2 tiles,
+ * tile t rendered on device t % N; per frame there is exactly ONE exchange — every peer sends its compact tile buffer to
+ * device 0 over its own xGMI link (RCCL ncclSend / ncclRecv in one group, resolved with dlopen at mi_multi_create) — then the
+ * un-permute and the tone-map run on device 0.  The image is bit-identical for every N (the RNG is keyed by the global
+ * pixel index).  `devices` = NULL means 0 .. n_devices-1.  mi_multi_render: as mi_render; opts->rank / world are ignored;
+ * stats->kernel_ms is the slowest device's pipeline pass, stats->total_ms the wall time of the call. */
+typedef struct mi_multi mi_multi;
+int  mi_multi_create(int n_devices, const int* devices, mi_multi** out);
+void mi_multi_destroy(mi_multi* m);
+int  mi_multi_device_count(const mi_multi* m);
+int  mi_multi_scene_upload(mi_multi* m, const mi_scene_desc* scene);
+int  mi_multi_reserve(mi_multi* m, const mi_camera_desc* cam, uint64_t max_state_bytes);
+int  mi_multi_render(mi_multi* m, const mi_camera_desc* cam, const mi_render_opts* opts,
+                     float* out_rgb_f32, uint8_t* out_rgb_u8, uint32_t* out_sig, mi_stats* stats);
 
 /* Thread-local message of the most recent failure in this thread. */
 const char* mi_last_error(void);

@@ -1,0 +1,207 @@
+// two_stage_check.cpp — CPU check of the exact two-stage mesh traversal (TEST INFRASTRUCTURE, compiled by
+// tests/test_two_stage_host.py with g++ -ffp-contract=off).  It builds the reference tree and the F-tree with the
+// product's own builders (cs397raytracingsp22_amd/csrc/bvh_build.hpp), then throws rays at the mesh and compares, bit for bit,
+//     (A) the reference walk: BVHNode::intersect_ray (geometry.rs:94-119) as the stackless skip-link walk, with
+//     (B) pass 1 — F-tree walk with the per-ray padding of two_stage_pad, the reference's own Moller-Trumbore test on the
+//         triangles of every leaf reached, passing triangles collected as candidates — and pass 2 — the reference's
+//         depth-first walk REPLAYED over the union of the root-to-candidate paths only, in index order, with the running bound.
+// Ray families include the adversarial ones for the padding bound: rays almost IN a triangle's plane (grazing), through
+// vertices and along edges, from far away, with tiny and huge |d|.
+// Prints one JSON line of work statistics.  usage: two_stage_check <mesh.bin> <scale> <n_rays> <seed>
+//   mesh.bin: int32 n_vertices, int32 n_triangles, float positions[3 nv], uint32 indices[3 nt]; positions are multiplied by <scale>
+#include <cstdio>
+#include <cstdlib>
+#include <climits>
+#include <cstring>
+#include <random>
+#include <vector>
+#include "../../cs397raytracingsp22_amd/csrc/bvh_build.hpp"
+
+using namespace pt::build;
+
+struct R3 { float x, y, z; };
+static inline R3 sub(R3 a, R3 b) { return R3{ a.x - b.x, a.y - b.y, a.z - b.z }; }
+static inline float dot(R3 a, R3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+static inline R3 cross(R3 a, R3 b) { return R3{ a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x }; }
+
+// AABB::intersect_ray geometry.rs:52-79 (single final reject: same decision, see pt_kernels.hip slab)
+static bool slab(const float* n, R3 o, R3 inv, float t_min, float t_max) {
+    float tmin = t_min, tmax = t_max;
+    const float bmin[3] = { n[0], n[1], n[2] }, bmax[3] = { n[4], n[5], n[6] };
+    const float oo[3] = { o.x, o.y, o.z }, ii[3] = { inv.x, inv.y, inv.z };
+    for (int a = 0; a < 3; a++) {
+        const float t0 = (bmin[a] - oo[a]) * ii[a], t1 = (bmax[a] - oo[a]) * ii[a];
+        const bool sw = ii[a] < 0.0f;
+        const float ta = sw ? t1 : t0, tb = sw ? t0 : t1;
+        tmin = fmaxf(ta, tmin); tmax = fminf(tb, tmax);
+    }
+    return !(tmax <= tmin);
+}
+static bool tri_t(R3 o, R3 d, const float* T, float t_min, float t_max, float& t_out) {
+    const R3 a{ T[0], T[1], T[2] }, e1{ T[4], T[5], T[6] }, e2{ T[8], T[9], T[10] };
+    const R3 q = cross(d, e2);
+    const float g = dot(e1, q), f = 1.0f / g;
+    const R3 s = sub(o, a);
+    const float u = f * dot(s, q);
+    const R3 r = cross(s, e1);
+    const float v = f * dot(d, r), t = f * dot(e2, r);
+    t_out = t;
+    return !((fabsf(g) < 0.0001f) | (u < 0.0f) | (v < 0.0f) | (u + v > 1.0f) | (t < t_min) | (t > t_max));
+}
+static int ileaf(const float* n) { int v; memcpy(&v, &n[7], 4); return v; }
+static int iskip(const float* n) { int v; memcpy(&v, &n[3], 4); return v; }
+
+int main(int argc, char** argv) {
+    if (argc < 5) { fprintf(stderr, "usage\n"); return 2; }
+    FILE* f = fopen(argv[1], "rb");
+    if (!f) { perror("mesh"); return 2; }
+    int nv = 0, nt = 0;
+    if (fread(&nv, 4, 1, f) != 1 || fread(&nt, 4, 1, f) != 1) return 2;
+    std::vector<float> pos((size_t)nv * 3); std::vector<uint32_t> idx((size_t)nt * 3);
+    if (fread(pos.data(), 4, pos.size(), f) != pos.size() || fread(idx.data(), 4, idx.size(), f) != idx.size()) return 2;
+    fclose(f);
+    const float scale = (float)atof(argv[2]); const long n_rays = atol(argv[3]); const unsigned seed = (unsigned)atoi(argv[4]);
+    for (float& p : pos) p *= scale;
+
+    std::vector<float> nodes, fnodes, ftris, tris((size_t)nt * 12, 0.0f);
+    RefTree rt{ pos.data(), idx.data(), &nodes };
+    rt.build(0, nt);
+    for (int t = 0; t < nt; t++) {
+        const V3 a = rt.vpos(t, 0), b = rt.vpos(t, 1), c = rt.vpos(t, 2);
+        float* T = &tris[(size_t)t * 12];
+        T[0] = a.x; T[1] = a.y; T[2] = a.z; T[4] = b.x - a.x; T[5] = b.y - a.y; T[6] = b.z - a.z; T[8] = c.x - a.x; T[9] = c.y - a.y; T[10] = c.z - a.z;
+    }
+    FTree ft{ tris.data(), nt, &fnodes, &ftris, 0, 2, {}, {}, {} };
+    const FConst fc = ft.run();
+    const int n_ref = (int)(nodes.size() / 8), n_f = (int)(fnodes.size() / 8);
+    const Box root = get_box(nodes.data());
+
+    std::mt19937 rng(seed);
+    std::uniform_real_distribution<float> U(-1.0f, 1.0f);
+    const R3 c{ 0.5f * (root.mn.x + root.mx.x), 0.5f * (root.mn.y + root.mx.y), 0.5f * (root.mn.z + root.mx.z) };
+    const float rad = 0.5f * sqrtf((root.mx.x - root.mn.x) * (root.mx.x - root.mn.x) + (root.mx.y - root.mn.y) * (root.mx.y - root.mn.y) +
+                                   (root.mx.z - root.mn.z) * (root.mx.z - root.mn.z));
+    long mismatches = 0, hits = 0, entered = 0, fallback = 0;
+    double ref_box = 0, ref_tri = 0, f_nodes = 0, f_leaves = 0, f_tri = 0, n_cand = 0, rp_slabs = 0, max_cand = 0, overflow8 = 0;
+    const float t_min = 0.001f;
+    auto vert = [&](R3& p) { const float* q = &pos[3 * (size_t)(rng() % (unsigned)nv)]; p = R3{ q[0], q[1], q[2] }; };
+    for (long r = 0; r < n_rays; r++) {
+        R3 o, d;
+        const int mode = (int)(r % 12);
+        float t_max = 100.0f;
+        if (mode == 0 || mode == 6 || mode == 7) {            // from outside toward the mesh; 6: tiny |d|, 7: huge |d|, short range
+            R3 w{ U(rng), U(rng), U(rng) }; const float l = sqrtf(dot(w, w)) + 1e-9f; const float k = rad * (1.2f + 2.0f * fabsf(U(rng))) / l;
+            o = R3{ c.x + w.x * k, c.y + w.y * k, c.z + w.z * k };
+            R3 tgt{ c.x + 0.8f * rad * U(rng), c.y + 0.8f * rad * U(rng), c.z + 0.8f * rad * U(rng) }; d = sub(tgt, o);
+            const float sc = (mode == 6 ? 0.01f : mode == 7 ? 37.0f : 1.0f) / (sqrtf(dot(d, d)) + 1e-20f); d = R3{ d.x * sc, d.y * sc, d.z * sc };
+            if (mode == 7) t_max = 3.0f;
+        } else if (mode == 1 || mode == 5) {                  // from a vertex (secondary rays start ON the surface), random in-ball direction
+            vert(o); d = R3{ U(rng), U(rng), U(rng) };
+        } else if (mode == 2) {                               // from inside
+            o = R3{ c.x + 0.3f * rad * U(rng), c.y + 0.3f * rad * U(rng), c.z + 0.3f * rad * U(rng) }; d = R3{ U(rng), U(rng), U(rng) };
+        } else if (mode == 3) {                               // axis-aligned through a vertex (zeros in d: inf in 1/d)
+            d = R3{ 0, 0, 0 }; const int ax = (int)(rng() % 3); (ax == 0 ? d.x : ax == 1 ? d.y : d.z) = (rng() & 1) ? 1.0f : -1.0f;
+            R3 p; vert(p); o = R3{ p.x - d.x * rad * 2, p.y - d.y * rad * 2, p.z - d.z * rad * 2 };
+        } else if (mode == 4) {                               // vertex to vertex: through vertices and along edges
+            R3 p; vert(o); vert(p); d = sub(p, o); const float k = 1.0f + 0.5f * U(rng); o = R3{ o.x - d.x * k, o.y - d.y * k, o.z - d.z * k };
+        } else {                                              // GRAZING: a ray (almost) in the plane of a random triangle, aimed near or far from it
+            const float* T = &tris[(size_t)(rng() % (unsigned)nt) * 12];
+            const R3 a{ T[0], T[1], T[2] }, e1{ T[4], T[5], T[6] }, e2{ T[8], T[9], T[10] };
+            const R3 n = cross(e1, e2);
+            const float w1 = U(rng) * (mode == 8 ? 1.0f : 30.0f), w2 = U(rng) * (mode == 8 ? 1.0f : 30.0f);
+            const R3 through{ a.x + w1 * e1.x + w2 * e2.x, a.y + w1 * e1.y + w2 * e2.y, a.z + w1 * e1.z + w2 * e2.z };
+            const float a1 = U(rng), a2 = U(rng);
+            R3 dir{ a1 * e1.x + a2 * e2.x, a1 * e1.y + a2 * e2.y, a1 * e1.z + a2 * e2.z };
+            const float tilt = (mode == 11 ? 1e-3f : mode == 10 ? 1e-6f : 0.0f) * U(rng) * sqrtf(dot(dir, dir)) / (sqrtf(dot(n, n)) + 1e-30f);
+            dir = R3{ dir.x + tilt * n.x, dir.y + tilt * n.y, dir.z + tilt * n.z };
+            const float k = 2.0f + 3.0f * fabsf(U(rng));
+            o = R3{ through.x - dir.x * k, through.y - dir.y * k, through.z - dir.z * k }; d = dir;
+        }
+        const R3 inv{ 1.0f / d.x, 1.0f / d.y, 1.0f / d.z };
+
+        // (A) reference walk
+        float bt = t_max; int btri = -1;
+        bool ent = false;
+        {
+            int i = 0;
+            const bool root_leaf = ileaf(nodes.data()) >= 0;
+            if (!root_leaf) { ref_box++; if (!slab(nodes.data(), o, inv, t_min, t_max)) i = n_ref; else i = 1; }
+            if (i < n_ref) { entered++; ent = true; }
+            while (i < n_ref) {
+                const float* n = &nodes[(size_t)i * 8];
+                const int tri = ileaf(n);
+                if (tri >= 0) { float t; ref_tri++; if (tri_t(o, d, &tris[(size_t)tri * 12], t_min, bt, t)) { bt = t; btri = tri; } i++; }
+                else { ref_box++; i = slab(n, o, inv, t_min, bt) ? i + 1 : iskip(n); }
+            }
+        }
+        // (B) two-stage (only rays that pass the root test are queued for a mesh walk)
+        float wt = t_max; int wtri = -1;
+        if (ent) {
+            const float of[3] = { o.x, o.y, o.z }, df[3] = { d.x, d.y, d.z };
+            FPad pad;
+            if (!two_stage_pad(fc, of, df, t_max, &pad)) { fallback++; wt = bt; wtri = btri; }
+            else {
+                struct Cand { float t; int tri; };
+                std::vector<Cand> cands;
+                // padded slab: bmin against o + rho, bmax against o - rho  ==  (bmin - rho, bmax + rho) against o
+                const R3 op{ o.x + pad.rho, o.y + pad.rho, o.z + pad.rho }, om{ o.x - pad.rho, o.y - pad.rho, o.z - pad.rho };
+                const float t_lo = t_min - pad.dt, t_hi = t_max + pad.dt;
+                int i = 0;
+                while (i < n_f) {
+                    const float* n = &fnodes[(size_t)i * 8];
+                    f_nodes++;
+                    float tmin = t_lo, tmax = t_hi;
+                    const float opv[3] = { op.x, op.y, op.z }, omv[3] = { om.x, om.y, om.z }, ii[3] = { inv.x, inv.y, inv.z };
+                    for (int a = 0; a < 3; a++) {
+                        const float t0 = (n[a] - opv[a]) * ii[a], t1 = (n[4 + a] - omv[a]) * ii[a];
+                        const bool sw = ii[a] < 0.0f;
+                        const float ta = sw ? t1 : t0, tb = sw ? t0 : t1;
+                        tmin = fmaxf(ta, tmin); tmax = fminf(tb, tmax);
+                    }
+                    if (tmax <= tmin) { i = iskip(n); continue; }
+                    const int leaf = ileaf(n);
+                    if (leaf >= 0) {
+                        f_leaves++;
+                        const int first = leaf >> 3, count = (leaf & 7) + 1;
+                        for (int k = 0; k < count; k++) {
+                            const float* T = &ftris[(size_t)(first + k) * 12];
+                            int tri; memcpy(&tri, &T[3], 4);
+                            float t; f_tri++;
+                            if (tri_t(o, d, T, t_min, t_max, t)) cands.push_back(Cand{ t, tri });
+                        }
+                    }
+                    i++;
+                }
+                n_cand += (double)cands.size(); if ((double)cands.size() > max_cand) max_cand = (double)cands.size(); if (cands.size() > 8) overflow8++;
+                std::sort(cands.begin(), cands.end(), [](const Cand& a, const Cand& b) { return a.tri < b.tri; });
+                int prev = -1, fail_depth = INT_MAX;
+                for (const Cand& cd : cands) {
+                    int s = 0, e = nt, me = 0, depth = 0, new_fail = INT_MAX; bool dead = false;
+                    while (e - s > 1) {
+                        const bool shared = prev >= s && prev < e;
+                        if (shared) { if (depth == fail_depth) { dead = true; new_fail = fail_depth; break; } }
+                        else { rp_slabs++; if (!slab(&nodes[(size_t)me * 8], o, inv, t_min, wt)) { dead = true; new_fail = depth; break; } }
+                        const int mid = s + (e - s) / 2;
+                        if (cd.tri < mid) { me = me + 1; e = mid; } else { me = me + 2 * (mid - s); s = mid; }
+                        depth++;
+                    }
+                    fail_depth = dead ? new_fail : INT_MAX; prev = cd.tri;
+                    if (!dead && cd.t <= wt) { wt = cd.t; wtri = cd.tri; }
+                }
+            }
+        }
+        if (btri >= 0) hits++;
+        uint32_t a, b; memcpy(&a, &bt, 4); memcpy(&b, &wt, 4);
+        if (btri != wtri || (btri >= 0 && a != b)) {
+            if (mismatches < 5) fprintf(stderr, "MISMATCH ray %ld mode %d: ref (%g, %d) two-stage (%g, %d)\n", r, mode, bt, btri, wt, wtri);
+            mismatches++;
+        }
+    }
+    const double e = (entered - fallback) > 0 ? (double)(entered - fallback) : 1.0;
+    printf("{\"tris\": %d, \"ref_nodes\": %d, \"f_nodes\": %d, \"scale\": %g, \"E2\": %g, \"L\": %g, \"rays\": %ld, \"entered\": %ld, \"fallback\": %ld, \"hits\": %ld, \"mismatches\": %ld, "
+           "\"ref_box_per_entry\": %.2f, \"ref_tri_per_entry\": %.2f, \"f_nodes_per_entry\": %.2f, \"f_leaves_per_entry\": %.2f, \"f_tri_per_entry\": %.2f, "
+           "\"cands_per_entry\": %.3f, \"max_cands\": %.0f, \"rays_over_8_cands\": %.0f, \"replay_slabs_per_entry\": %.2f}\n",
+           nt, n_ref, n_f, scale, fc.E2, fc.L, n_rays, entered, fallback, hits, mismatches, ref_box / (entered ? (double)entered : 1.0), ref_tri / (entered ? (double)entered : 1.0),
+           f_nodes / e, f_leaves / e, f_tri / e, n_cand / e, max_cand, overflow8, rp_slabs / e);
+    return mismatches ? 1 : 0;
+}

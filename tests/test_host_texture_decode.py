@@ -1,0 +1,133 @@
+"""C++ host texture decode (cs397raytracingsp22_amd/host/texture.hpp, the mirror of Texture::load_from_file,
+texture.rs:16-25): PNG and TGA decode byte for byte like PIL's `.convert("RGB")` (= what the reference's
+`get_pixel(..).to_rgb()` yields for 8-bit files); anything it cannot decode gives nullopt, the reference's None."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+from PIL import Image
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF_TEX = "/root/reference/texture"
+
+
+@pytest.fixture(scope="module")
+def decoder(tmp_path_factory):
+    exe = tmp_path_factory.mktemp("tex") / "texture_decode_check"
+    subprocess.run(["g++", "-O2", "-std=c++17", "-Wall", os.path.join(ROOT, "tests", "cpp", "texture_decode_check.cpp"),
+                    "-o", str(exe), "-lz"], check=True)
+    return str(exe)
+
+
+def decode(decoder, path, tmp_path):
+    out = tmp_path / "out.raw"
+    r = subprocess.run([decoder, str(path), str(out)])
+    if r.returncode == 3:
+        return None
+    assert r.returncode == 0
+    raw = open(out, "rb").read()
+    head, body = raw.split(b"\n", 1)
+    w, h = (int(v) for v in head.split())
+    return np.frombuffer(body, np.uint8).reshape(h, w, 3)
+
+
+def pil_rgb(path):
+    return np.asarray(Image.open(path).convert("RGB"))
+
+
+@pytest.mark.parametrize("name", ["green.png", "white.png", "normal_test.png"])
+def test_reference_png_assets_decode_exactly(decoder, tmp_path, name):
+    path = os.path.join(REF_TEX, name)
+    if not os.path.exists(path):
+        pytest.skip("reference assets are not on this machine")
+    assert np.array_equal(decode(decoder, path, tmp_path), pil_rgb(path))
+
+
+def synthetic(seed, w, h, mode):
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w]
+    base = np.stack([(xx * 7 + yy * 3) % 256, (xx * 2 + yy * 11) % 256, (xx + yy) % 256, (xx * 5) % 256], axis=2).astype(np.uint8)
+    base[::3, ::4] = rng.integers(0, 256, base[::3, ::4].shape, dtype=np.uint8)
+    if mode == "RGB":
+        return Image.fromarray(base[:, :, :3], "RGB")
+    if mode == "RGBA":
+        return Image.fromarray(base, "RGBA")
+    if mode == "L":
+        return Image.fromarray(base[:, :, 0], "L")
+    if mode == "LA":
+        return Image.fromarray(base[:, :, :2], "LA")
+    if mode == "P":
+        return Image.fromarray(base[:, :, :3], "RGB").quantize(colors=200)
+    if mode == "P4":
+        return Image.fromarray(base[:, :, :3], "RGB").quantize(colors=16)
+    if mode == "1":
+        return Image.fromarray(base[:, :, 0] > 127)
+    raise ValueError(mode)
+
+
+@pytest.mark.parametrize("mode", ["RGB", "RGBA", "L", "LA", "P", "P4", "1"])
+@pytest.mark.parametrize("size", [(64, 48), (37, 53), (1, 1), (9, 3)])
+def test_png_colour_types_and_ragged_sizes(decoder, tmp_path, mode, size):
+    img = synthetic(hash(mode) % 1000, size[0], size[1], mode)
+    p = tmp_path / f"t_{mode}.png"
+    kw = {"bits": 4} if mode == "P4" else {}
+    img.save(p, optimize=(size[0] > 9), **kw)
+    assert np.array_equal(decode(decoder, p, tmp_path), pil_rgb(p))
+
+
+def test_png_interlaced(decoder, tmp_path):
+    """Adam7: PIL cannot write it, so one is assembled here by hand (7 passes, filter 0) from a known image."""
+    import struct
+    import zlib
+    w, h = 23, 17
+    img = np.asarray(synthetic(5, w, h, "RGB"))
+    passes = [(0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2)]
+    raw = b""
+    for x0, y0, dx, dy in passes:
+        sub = img[y0::dy, x0::dx]
+        if sub.size:
+            for row in sub:
+                raw += b"\x00" + row.tobytes()
+
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xffffffff)
+    png = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 2, 0, 0, 1)) + chunk(b"IDAT", zlib.compress(raw)) + chunk(b"IEND", b"")
+    p = tmp_path / "a7.png"
+    p.write_bytes(png)
+    assert np.array_equal(pil_rgb(p), img)                    # PIL reads it: the hand-made file is a valid PNG
+    assert np.array_equal(decode(decoder, p, tmp_path), img)
+    bad = bytearray(png)
+    bad[60] ^= 0x55                                            # corrupt the IDAT payload: CRC mismatch -> None
+    q = tmp_path / "bad.png"
+    q.write_bytes(bytes(bad))
+    assert decode(decoder, q, tmp_path) is None
+
+
+@pytest.mark.parametrize("mode,rle", [("RGB", False), ("RGB", True), ("RGBA", False), ("RGBA", True), ("L", False), ("L", True), ("P", False)])
+def test_tga_variants(decoder, tmp_path, mode, rle):
+    """The drone's five maps are TGA files (absent from the reference, .MISSING_LARGE_BLOBS): true-colour / grey / colour-mapped,
+    raw and run-length encoded, written by PIL (bottom-left origin) and by hand (top-left origin)."""
+    img = synthetic(11, 61, 45, mode)
+    p = tmp_path / f"t_{mode}_{rle}.tga"
+    img.save(p, compression="tga_rle" if rle else None)
+    assert np.array_equal(decode(decoder, p, tmp_path), pil_rgb(p))
+    if mode == "RGB" and not rle:                              # same pixels, top-left origin flag set and rows reordered
+        d = bytearray(p.read_bytes())
+        w, h = 61, 45
+        body = np.frombuffer(bytes(d[18:18 + w * h * 3]), np.uint8).reshape(h, w, 3)[::-1]
+        d[17] |= 0x20
+        d[18:18 + w * h * 3] = body.tobytes()
+        q = tmp_path / "top.tga"
+        q.write_bytes(bytes(d))
+        assert np.array_equal(decode(decoder, q, tmp_path), pil_rgb(p))
+
+
+def test_undecodable_files_give_none(decoder, tmp_path):
+    p = tmp_path / "noise.bin"
+    p.write_bytes(bytes(range(7)))
+    assert decode(decoder, p, tmp_path) is None
+    assert decode(decoder, tmp_path / "does_not_exist.png", tmp_path) is None
+    jpg = tmp_path / "x.jpg"
+    synthetic(1, 16, 16, "RGB").save(jpg)
+    assert decode(decoder, jpg, tmp_path) is None              # JPEG: documented as not decoded by the compiled mirror
