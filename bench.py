@@ -124,19 +124,21 @@ def cpu_baseline(sc, flat):
         lib, build = None, f"-O2 portable (native build failed: {type(e).__name__})"
     o = orc_py.OracleScene(flat, lib=lib)
     W, H = cam.screen_width, cam.screen_height
-    # Time-boxed: successive sets of rows, each set spread evenly over the image height (same mix of cheap and
-    # expensive pixels as the whole frame), until about 5 s of CPU work have been done.
-    rows_per_set = max(2 * threads, 16)
-    stride = max(1, H // rows_per_set)
-    rows_per_set = min(rows_per_set, H // stride)
-    n, sets, dt = 0, 0, 0.0
-    while dt < 5.0 and sets < stride:
+    # Bounded sample: sets of rows spread evenly over the image height (the same mix of cheap and expensive pixels as
+    # the whole frame).  A short calibration set sizes the measured one to about 5 s of CPU work.
+    def run(first_row, n_rows, stride):
         t0 = time.perf_counter()
-        o.render(cam, seed=1, threads=threads, window=(0, sets, W, rows_per_set), row_stride=stride,
-                 want_u8=False, want_sig=False)
-        dt += time.perf_counter() - t0
-        n += W * rows_per_set * cam.aa_sample_count
-        sets += 1
+        o.render(cam, seed=1, threads=threads, window=(0, first_row, W, n_rows), row_stride=stride, want_u8=False, want_sig=False)
+        return time.perf_counter() - t0
+    cal_rows = min(H, max(threads, 8))
+    cal_stride = max(1, H // cal_rows)
+    t_cal = run(0, cal_rows, cal_stride)
+    rows = int(min(H - cal_rows, max(cal_rows, cal_rows * 5.0 / max(t_cal, 1e-3))))
+    rows = max(threads, rows - rows % max(1, threads))
+    stride = max(1, H // rows)
+    rows = min(rows, H // stride)
+    dt = run(min(1, stride - 1), rows, stride)
+    n = W * rows * cam.aa_sample_count
     model = "unknown CPU"
     try:
         with open("/proc/cpuinfo") as fh:
@@ -146,10 +148,10 @@ def cpu_baseline(sc, flat):
                     break
     except OSError:
         pass
-    rows = rows_per_set * sets
     return {"value": n / dt / 1e6, "unit": "Msamples/s", "cores": threads, "kind": "port", "cpu": model, "build": build,
-            "sample": f"{rows} full-width rows ({sets} sets of every {stride}th row) of the same {W}x{H} frame, all {cam.aa_sample_count} spp: "
-                      f"{n} samples in {dt:.1f} s (plain-C oracle, one task per scanline like rayon, tracing.rs:228)"}
+            "sample": f"{rows} full-width rows (every {stride}th row) of the same {W}x{H} frame, all {cam.aa_sample_count} spp: "
+                      f"{n} samples in {dt:.1f} s after a {cal_rows}-row calibration pass (plain-C oracle, one task per scanline "
+                      f"like rayon, tracing.rs:228; cores = worker threads = affinity mask capped by the cgroup CPU quota)"}
 
 
 def main():

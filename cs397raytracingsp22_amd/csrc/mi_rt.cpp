@@ -138,6 +138,7 @@ struct mi_ctx {
         uint32_t vote_t = 2, vote_a = 1, k_steps = 8;   // voted megakernel
         uint32_t lds_pad = 0;                           // occupancy experiments
         uint32_t refill_min = 32;                       // wf_trav: refill idle lanes when at least this many are idle
+        uint32_t fuse_max = 1, fuse_min = 32;           // wf_main: in-launch continuation (rounds, lanes needed)
         int trav_lds = -1;                              // wf_trav LDS mode override (-1 = automatic)
         int trav_bpc = 0;                               // wf_trav blocks per CU override (0 = automatic)
         int kernel_timing = -1;                         // per-launch HIP events: -1 = single-rank renders only
@@ -181,6 +182,7 @@ static int ctx_init(mi_ctx* c, const hipDeviceProp_t& prop) {
     env_u("MI_RT_VOTE_T", t.vote_t); env_u("MI_RT_VOTE_A", t.vote_a); env_u("MI_RT_KSTEPS", t.k_steps);
     if (const char* e = getenv("MI_RT_LDS_PAD_KB")) t.lds_pad = (uint32_t)atoi(e) * 1024u;
     env_u("MI_RT_WF_REFILL", t.refill_min);
+    env_u("MI_RT_WF_FUSE_MAX", t.fuse_max); env_u("MI_RT_WF_FUSE_MIN", t.fuse_min);
     env_i("MI_RT_WF_TRAV_LDS", t.trav_lds); env_i("MI_RT_WF_TRAV_BPC", t.trav_bpc); env_i("MI_RT_WF_KERNEL_TIMING", t.kernel_timing);
     t.global_bvh = getenv("MI_RT_GLOBAL_BVH") != nullptr;
     t.wf_stamps = getenv("MI_RT_WF_STAMPS") != nullptr;
@@ -894,6 +896,7 @@ static int render_tiles_wavefront(mi_ctx* c, const K1Args& k, const mi_camera_de
     a.diag = nullptr;           // developer builds (-DPT_WF_STAMPS): phase stamps of wf_main
     if (c->tune.wf_stamps) { a.diag = c->d_diag; HIP_TRY(hipMemsetAsync(c->d_diag, 0, 16 * sizeof(unsigned long long), stream)); }
     a.refill_min = c->tune.refill_min;
+    a.fuse_max = c->tune.fuse_max; a.fuse_min = c->tune.fuse_min < 1 ? 1 : c->tune.fuse_min;
     // Which meshes are walked how: the two-stage meshes (wf_trav_f + wf_replay), the rest through the reference's tree (wf_trav).
     const uint32_t all_meshes = c->S.n_meshes >= 32 ? 0xffffffffu : ((1u << c->S.n_meshes) - 1u);
     const uint32_t ts_mask = two_stage_mask(c, flags) & all_meshes;

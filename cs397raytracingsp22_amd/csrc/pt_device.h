@@ -219,6 +219,8 @@ struct WfArgs {
     uint32_t s_count;     // samples per pixel in this batch
     uint32_t npix;        // tile-major pixels of this rank = tiles_padded * 1024
     uint32_t refill_min;  // wf_trav: refill idle lanes only when at least this many are idle (amortises the gather latency)
+    uint32_t fuse_max;    // wf_main: at most this many further shade + intersect rounds inside one launch ...
+    uint32_t fuse_min;    // ... each taken only while at least this many lanes of the wave can continue
     // Every shard region is filled from BOTH ENDS: class A (the next shade is a plain Triangle /
     // Plane hit: the common, cheap case) grows from the front, class B (sphere hits, rays waiting
     // for a mesh walk, volumes) from the back; A + B can never exceed the region.  The next pass

@@ -1419,7 +1419,23 @@ __global__ __launch_bounds__(kBlock, PT_MAIN_WAVES) void wf_main(WfArgs A) {
             best.u = q5.x; best.v = q5.y;
         }
         WF_STAMP(2);
-        if (alive) {
+    }
+
+    WF_STAMP(3);
+    // ---- shade the pending hit, intersect the new ray — and, while enough lanes of the wave can, do it again ----
+    // A path whose new ray entered no mesh root has its next hit in registers already: shading it here, in the same
+    // launch, saves that path one round trip through the HBM path state (72 B out + 72 B back) and one pass' worth of
+    // block look-up, state loads and stores.  The wave votes: it goes on only while at least `fuse_min` of its lanes
+    // would continue (the others — ended, or waiting for a mesh walk — sit the extra trips out), at most `fuse_max`
+    // times.  Per path the order of evaluation is untouched: same shading, same intersection, same RNG stream.
+    bool pending = (A.iter0 == 0u) && alive;            // a hit record was loaded: Scene::shade_ray, one level (tracing.rs:305-321)
+    bool need = (A.iter0 != 0u) && alive;               // a fresh ray needs Scene::intersect_ray
+    bool first = true, enters = false;
+    int tm = 0;
+    uint32_t fuse_left = A.fuse_max;
+    if (A.iter0) { best.obj = -1; best.t = 0.0f; best.tri = -1; best.u = best.v = 0.0f; }
+    for (;;) {
+        if (pending) {
             bool end_path;
             if (best.obj < 0) {
                 end_path = true;
@@ -1445,27 +1461,32 @@ __global__ __launch_bounds__(kBlock, PT_MAIN_WAVES) void wf_main(WfArgs A) {
                 A.samp[(size_t)(sample - A.s_base) * A.npix + pix] = make_float4(P.L.x, P.L.y, P.L.z, __uint_as_float(P.sig));
                 alive = false;
             }
+            need = alive;
+            pending = false;
         }
-    }
-
-    WF_STAMP(3);
-    // ---- Scene::intersect_ray for the new ray: object list, then the mesh roots ----
-    int tm = 0;
-    bool enters = false;
-    best.obj = -1; best.t = 0.0f; best.tri = -1; best.u = best.v = 0.0f;
-    if (alive) {
-        if (A.iter0 && A.tile_mask) intersect_list_masked(S, list_mask, P.o, P.d, t_min, t_max, P.rng, best);
-        else intersect_list(S, P.o, P.d, t_min, t_max, P.rng, best);
-        f3 oo, od, inv; int ti, tend, ttb;
-        enters = enter_next_mesh(S, B, tm, P.o, P.d, t_min, t_max, oo, od, inv, ti, tend, ttb, (uint32_t)mesh_word);
-    }
-    // A ray that hits no object and enters no mesh ends its path at the next shade_ray level
-    // (tracing.rs:306, background = 0).  Do that level now — same operations, same RNG state —
-    // instead of streaming the path through HBM once more just to terminate it.
-    if (alive && best.obj < 0 && !enters) {
-        if (SIG) P.sig = sig_end_miss(P.sig, P.rng);
-        A.samp[(size_t)(sample - A.s_base) * A.npix + pix] = make_float4(P.L.x, P.L.y, P.L.z, __uint_as_float(P.sig));
-        alive = false;
+        // ---- Scene::intersect_ray for the new ray: object list, then the mesh roots ----
+        if (need) {
+            tm = 0; enters = false;
+            best.obj = -1; best.t = 0.0f; best.tri = -1; best.u = best.v = 0.0f;
+            if (first && A.iter0 && A.tile_mask) intersect_list_masked(S, list_mask, P.o, P.d, t_min, t_max, P.rng, best);
+            else intersect_list(S, P.o, P.d, t_min, t_max, P.rng, best);
+            f3 oo, od, inv; int ti, tend, ttb;
+            enters = enter_next_mesh(S, B, tm, P.o, P.d, t_min, t_max, oo, od, inv, ti, tend, ttb, first ? (uint32_t)mesh_word : 0xffffffffu);
+            // A ray that hits no object and enters no mesh ends its path at the next shade_ray level
+            // (tracing.rs:306, background = 0).  Do that level now — same operations, same RNG state —
+            // instead of streaming the path through HBM once more just to terminate it.
+            if (best.obj < 0 && !enters) {
+                if (SIG) P.sig = sig_end_miss(P.sig, P.rng);
+                A.samp[(size_t)(sample - A.s_base) * A.npix + pix] = make_float4(P.L.x, P.L.y, P.L.z, __uint_as_float(P.sig));
+                alive = false;
+            }
+            need = false;
+        }
+        first = false;
+        const bool cont = alive && !enters;             // its hit is known: nothing left to wait for
+        if (fuse_left == 0u || (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(cont)) < A.fuse_min) break;
+        fuse_left--;
+        pending = cont;
     }
     WF_STAMP(4);
     // ---- compact the survivors into this block's shard region, class A from the front, class B

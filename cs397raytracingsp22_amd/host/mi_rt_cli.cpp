@@ -1,6 +1,6 @@
 // mi_rt_cli — C++ caller of the C ABI through the host mirror (tracing.hpp): builds the Cornell
 // box (+ optional OBJ mesh) from the reference's types, renders on GPU 0 and writes a binary PPM.
-//   mi_rt_cli <out.ppm> <width> <height> <spp> <depth> [mesh.obj]
+//   mi_rt_cli <out.ppm> <width> <height> <spp> <depth> [mesh.obj | -] [n_gpus]      (n_gpus: render through mi_multi_*)
 // Replaces the reference's run() (tracing.rs:354-548) as the compiled driver of the path.
 #include <cstdio>
 #include <cstdlib>
@@ -14,7 +14,8 @@ static void quad(std::vector<IntersectableRef>& o, Vec3 p0, Vec3 p1, Vec3 p2, Ve
 }
 
 int main(int argc, char** argv) {
-    if (argc < 6) { fprintf(stderr, "usage: %s out.ppm width height spp depth [mesh.obj]\n", argv[0]); return 2; }
+    if (argc < 6) { fprintf(stderr, "usage: %s out.ppm width height spp depth [mesh.obj | -] [n_gpus]\n", argv[0]); return 2; }
+    const int n_gpus = argc > 7 ? atoi(argv[7]) : 0;
     Scene sc;
     sc.camera.eyepoint = {0.0f, 3.0f, 6.6f};
     sc.camera.screen_width = (uint32_t)atoi(argv[2]); sc.camera.screen_height = (uint32_t)atoi(argv[3]);
@@ -32,18 +33,18 @@ int main(int argc, char** argv) {
     sc.objects.push_back(std::make_shared<Sphere>(Vec3{-1.4f, 1.0f, -0.5f}, 1.0f, std::make_shared<Metal>(Color{0.8f, 0.8f, 0.8f}, Color{0, 0, 0}, 0.1f)));
     sc.objects.push_back(std::make_shared<Sphere>(Vec3{1.4f, 1.0f, 0.8f}, 1.0f, std::make_shared<Dielectric>(1.5f)));
     try {
-        if (argc > 6)
+        if (argc > 6 && std::string(argv[6]) != "-")
             sc.objects.push_back(StaticMesh::load_from_file(argv[6], nullptr, nullptr, nullptr, nullptr, nullptr,
                                                             std::make_shared<Lambertian>(Color{0.5f, 0.02f, 0.5f}),
                                                             Matrix4::from_translation({0.0f, 0.9f, 0.0f}) * Matrix4::from_angle_x(-90.0f) * Matrix4::from_scale(2.2f)));
         mi_stats st{};
-        RgbImage img = sc.render_to_image(1, 0, &st);
+        RgbImage img = sc.render_to_image(1, 0, &st, nullptr, n_gpus);
         FILE* f = fopen(argv[1], "wb");
         if (!f) { perror(argv[1]); return 1; }
         fprintf(f, "P6\n%u %u\n255\n", img.width, img.height);
         fwrite(img.data.data(), 1, img.data.size(), f);
         fclose(f);
-        printf("caller=c++ samples=%llu kernel_ms=%.3f msamples_per_s=%.1f\n", (unsigned long long)st.samples, st.kernel_ms,
+        printf("caller=c++ gpus=%d samples=%llu kernel_ms=%.3f msamples_per_s=%.1f\n", n_gpus > 0 ? n_gpus : 1, (unsigned long long)st.samples, st.kernel_ms,
                st.samples / (st.kernel_ms * 1e3));
     } catch (const std::exception& e) { fprintf(stderr, "error: %s\n", e.what()); return 1; }
     return 0;

@@ -44,22 +44,35 @@ struct Scene {                                         // tracing.rs:213-218
     Vec3 ambient{0.1f, 0.1f, 0.1f};                    // Phong only (:292)
 
     // Scene::render_to_image (tracing.rs:221-263).  seed: the reference RNG is unseeded; device: HIP ordinal.
-    RgbImage render_to_image(uint32_t seed = 1, int device = 0, mi_stats* stats = nullptr, std::vector<float>* linear = nullptr) const {
+    // n_gpus > 0 renders on the first n_gpus devices of the node through mi_multi_* (tiles t % n, one RCCL fan-in per
+    // frame inside the library) — the drop-in for rayon's row parallelism (tracing.rs:228); the image is the same.
+    RgbImage render_to_image(uint32_t seed = 1, int device = 0, mi_stats* stats = nullptr, std::vector<float>* linear = nullptr,
+                             int n_gpus = 0) const {
         SceneBuilder sb;
         for (auto& o : objects) o->flatten(sb);
         mi_scene_desc d = sb.desc();
         for (int k = 0; k < 3; k++) { d.point_light_pos[k] = point_light_pos[k]; d.ambient[k] = ambient[k]; }
         mi_camera_desc cam = camera.flatten();
-        mi_ctx* ctx = nullptr;
-        mi_check(mi_ctx_create(device, &ctx));
         RgbImage img; img.width = camera.screen_width; img.height = camera.screen_height;
         img.data.resize((size_t)img.width * img.height * 3);
         if (linear) linear->resize(img.data.size());
         mi_render_opts opts{}; opts.seed = seed; opts.rank = 0; opts.world = 1;
-        int rc = mi_scene_upload(ctx, &d);
-        if (rc == MI_OK) rc = mi_render(ctx, &cam, &opts, linear ? linear->data() : nullptr, img.data.data(), nullptr, stats);
-        std::string err = rc == MI_OK ? "" : mi_last_error();
-        mi_ctx_destroy(ctx);
+        int rc; std::string err;
+        if (n_gpus > 0) {
+            mi_multi* m = nullptr;
+            mi_check(mi_multi_create(n_gpus, nullptr, &m));
+            rc = mi_multi_scene_upload(m, &d);
+            if (rc == MI_OK) rc = mi_multi_render(m, &cam, &opts, linear ? linear->data() : nullptr, img.data.data(), nullptr, stats);
+            err = rc == MI_OK ? "" : mi_last_error();
+            mi_multi_destroy(m);
+        } else {
+            mi_ctx* ctx = nullptr;
+            mi_check(mi_ctx_create(device, &ctx));
+            rc = mi_scene_upload(ctx, &d);
+            if (rc == MI_OK) rc = mi_render(ctx, &cam, &opts, linear ? linear->data() : nullptr, img.data.data(), nullptr, stats);
+            err = rc == MI_OK ? "" : mi_last_error();
+            mi_ctx_destroy(ctx);
+        }
         if (rc != MI_OK) throw std::runtime_error("mi_rt: " + err);
         return img;
     }

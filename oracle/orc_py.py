@@ -32,10 +32,29 @@ class orc_hit_rec(C.Structure):
 
 
 def usable_cores():
+    """Cores this process may actually use: the affinity mask, capped by the cgroup CPU quota (a GPU box shows every
+    core of the host in the mask but grants a share of them)."""
     try:
-        return max(1, min(len(os.sched_getaffinity(0)), 256))
+        n = len(os.sched_getaffinity(0))
     except AttributeError:
-        return max(1, min(os.cpu_count() or 1, 256))
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as fh:
+                parts = fh.read().split()
+            if path.endswith("cpu.max"):
+                if parts[0] != "max":
+                    n = min(n, max(1, int(round(int(parts[0]) / int(parts[1])))))
+            else:
+                quota = int(parts[0])
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fh:
+                    period = int(fh.read().split()[0])
+                if quota > 0:
+                    n = min(n, max(1, int(round(quota / period))))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, min(n, 256))
 
 
 def build(force=False):

@@ -32,6 +32,8 @@ use std::os::raw::{c_char, c_int, c_void};
 #[repr(C)] #[derive(Default)] pub struct mi_render_opts { pub seed: u32, pub rank: i32, pub world: i32, pub variant: i32, pub want_signature: i32, pub flags: u32, pub max_state_bytes: u64 }
 #[repr(C)] #[derive(Default)] pub struct mi_stats { pub samples: u64, pub pixels: u64, pub tiles: u32, pub tiles_padded: u32, pub kernel_ms: f32, pub total_ms: f32, pub scene_bytes: u32, pub scene_in_lds: u32 }
 pub enum mi_ctx {}
+pub enum mi_multi {}
+pub const MI_OPT_NO_TILE_MASKS: u32 = 1; pub const MI_OPT_REFERENCE_WALK: u32 = 2; pub const MI_OPT_TWO_STAGE: u32 = 4;
 
 #[link(name = "mi_rt")]
 extern "C" {
@@ -40,6 +42,17 @@ extern "C" {
     pub fn mi_scene_upload(ctx: *mut mi_ctx, scene: *const mi_scene_desc) -> c_int;
     pub fn mi_render(ctx: *mut mi_ctx, cam: *const mi_camera_desc, opts: *const mi_render_opts,
                      out_rgb_f32: *mut f32, out_rgb_u8: *mut u8, out_sig: *mut u32, stats: *mut mi_stats) -> c_int;
+    pub fn mi_reserve(ctx: *mut mi_ctx, cam: *const mi_camera_desc, world: i32, max_state_bytes: u64) -> c_int;
+    pub fn mi_last_kernel_ms(ctx: *mut mi_ctx, ms: *mut f32) -> c_int;
+    pub fn mi_abi_version() -> c_int;           // 3: assert at start-up that header and library agree
+    // N GPUs of one node behind one blocking call (RCCL fan-in inside the library)
+    pub fn mi_multi_create(n_devices: c_int, devices: *const c_int, out: *mut *mut mi_multi) -> c_int;
+    pub fn mi_multi_destroy(m: *mut mi_multi);
+    pub fn mi_multi_device_count(m: *const mi_multi) -> c_int;
+    pub fn mi_multi_scene_upload(m: *mut mi_multi, scene: *const mi_scene_desc) -> c_int;
+    pub fn mi_multi_reserve(m: *mut mi_multi, cam: *const mi_camera_desc, max_state_bytes: u64) -> c_int;
+    pub fn mi_multi_render(m: *mut mi_multi, cam: *const mi_camera_desc, opts: *const mi_render_opts,
+                           out_rgb_f32: *mut f32, out_rgb_u8: *mut u8, out_sig: *mut u32, stats: *mut mi_stats) -> c_int;
     pub fn mi_last_error() -> *const c_char;
 }
 

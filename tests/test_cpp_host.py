@@ -47,7 +47,7 @@ def test_cpp_caller_matches_python_caller(gpu_ctx, tmp_path):
     out = tmp_path / "c1.ppm"
     r = subprocess.run([CLI, str(out), "96", "80", "16", "8"], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
-    assert "caller=c++" in r.stdout
+    assert "caller=c++" in r.stdout and "gpus=1" in r.stdout
     sc = scenes.config1(96, 80, 16, 8)
     gpu_ctx.upload(sc.flatten())
     _, u8, _, _ = gpu_ctx.render(sc.camera, seed=1)
@@ -68,3 +68,15 @@ def test_cpp_caller_with_obj_mesh(gpu_ctx, tmp_path):
     # the C++ mirror composes the mesh transform / inverse with its own f32 arithmetic, so the
     # scene differs from the Python mirror's by ulps: same picture, not the same bytes
     assert float(np.abs(got - u8.astype(np.int32)).mean()) < 2.0
+
+
+@pytest.mark.gpu
+def test_cpp_caller_through_mi_multi(gpu_ctx, tmp_path):
+    """The compiled caller over mi_multi_* (one device here; RCCL is dlopen'ed and a one-device communicator built):
+    same bytes as the single-context call."""
+    a, b = tmp_path / "single.ppm", tmp_path / "multi.ppm"
+    r1 = subprocess.run([CLI, str(a), "96", "80", "16", "8"], capture_output=True, text=True)
+    r2 = subprocess.run([CLI, str(b), "96", "80", "16", "8", "-", "1"], capture_output=True, text=True)
+    assert r1.returncode == 0 and r2.returncode == 0, r1.stderr + r2.stderr
+    assert "gpus=1" in r2.stdout
+    assert np.array_equal(read_ppm(a), read_ppm(b))

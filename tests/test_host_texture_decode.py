@@ -1,6 +1,7 @@
 """C++ host texture decode (cs397raytracingsp22_amd/host/texture.hpp, the mirror of Texture::load_from_file,
-texture.rs:16-25): PNG and TGA decode byte for byte like PIL's `.convert("RGB")` (= what the reference's
-`get_pixel(..).to_rgb()` yields for 8-bit files); anything it cannot decode gives nullopt, the reference's None."""
+texture.rs:16-25): PNG, TGA and JPEG (baseline + progressive) decode byte for byte like PIL's `.convert("RGB")` — for PNG /
+TGA that is what the reference's `get_pixel(..).to_rgb()` yields; for JPEG it is libjpeg's result, from which the `image`
+crate's own decoder may differ by 1-2 LSB.  Anything it cannot decode gives nullopt, the reference's None."""
 import os
 import subprocess
 
@@ -128,6 +129,37 @@ def test_undecodable_files_give_none(decoder, tmp_path):
     p.write_bytes(bytes(range(7)))
     assert decode(decoder, p, tmp_path) is None
     assert decode(decoder, tmp_path / "does_not_exist.png", tmp_path) is None
-    jpg = tmp_path / "x.jpg"
-    synthetic(1, 16, 16, "RGB").save(jpg)
-    assert decode(decoder, jpg, tmp_path) is None              # JPEG: documented as not decoded by the compiled mirror
+    cmyk = tmp_path / "cmyk.jpg"
+    synthetic(1, 16, 16, "RGB").convert("CMYK").save(cmyk)
+    assert decode(decoder, cmyk, tmp_path) is None             # four components: documented as not decoded
+    trunc = tmp_path / "trunc.jpg"
+    good = tmp_path / "good.jpg"
+    synthetic(1, 64, 64, "RGB").save(good)
+    trunc.write_bytes(good.read_bytes()[:200])
+    assert decode(decoder, trunc, tmp_path) is None
+
+
+@pytest.mark.parametrize("name", ["earthmap.jpg", "normal_test.jpg", "magenta.jpg"])
+def test_reference_jpeg_assets_decode_like_libjpeg(decoder, tmp_path, name):
+    """Baseline 4:4:4, baseline 4:2:0 and PROGRESSIVE 4:2:0: bit-identical to PIL (libjpeg-turbo: islow IDCT, fancy upsampling)."""
+    path = os.path.join(REF_TEX, name)
+    if not os.path.exists(path):
+        pytest.skip("reference assets are not on this machine")
+    assert np.array_equal(decode(decoder, path, tmp_path), pil_rgb(path))
+
+
+@pytest.mark.parametrize("size", [(64, 48), (37, 53), (1, 1), (17, 9), (130, 66)])
+@pytest.mark.parametrize("kw", [dict(subsampling=0), dict(subsampling=1), dict(subsampling=2), dict(subsampling=2, progressive=True),
+                                dict(subsampling=0, progressive=True, quality=95), dict(subsampling=2, quality=30, optimize=True),
+                                dict(grey=True), dict(grey=True, progressive=True), dict(subsampling=2, restart_marker_blocks=3)])
+def test_jpeg_variants(decoder, tmp_path, size, kw):
+    kw = dict(kw)
+    img = synthetic(7, size[0], size[1], "L" if kw.pop("grey", False) else "RGB")
+    p = tmp_path / "t.jpg"
+    try:
+        img.save(p, **kw)
+    except (TypeError, OSError):
+        pytest.skip("this Pillow cannot write that variant")
+    got = decode(decoder, p, tmp_path)
+    assert got is not None
+    assert np.array_equal(got, pil_rgb(p))

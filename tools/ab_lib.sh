@@ -1,16 +1,8 @@
 #!/bin/bash
-# A/B of prebuilt library variants on ONE box: tools/ab_lib.sh tmp_variants/libA.so tmp_variants/libB.so ...
-run() { cp "$1" cs397raytracingsp22_amd/lib/libmi_rt.so; echo "RES [$1] $(python - <<PY
-import sys; sys.path.insert(0,".")
-import torch
-from cs397raytracingsp22_amd import Context, scenes
-sc = scenes.config2(1920,1080,256,10); ctx = Context(0); ctx.upload(sc.flatten()); ctx.reserve(sc.camera)
-best = None
-for i in range(4):
-    _,_,_,st = ctx.render(sc.camera, want_u8=False, variant=7)
-    p = ctx.last_pipeline_ms()
-    if best is None or st.kernel_ms < best[0]: best = (st.kernel_ms, p)
-print("%.1f ms" % best[0], {k: round(v,1) for k,v in best[1].items()})
-PY
-)"; }
-for rep in 1 2 3 4; do for e in "$@"; do run "$e"; done; done
+# A/B of prebuilt library variants on ONE box (same process recipe, library swapped in between):
+#   tools/ab_lib.sh "<probe.py args>" tmp_variants/libA.so tmp_variants/libB.so ...
+# Build variants with e.g.  MI_RT_EXTRA_FLAGS=-DPT_MAIN_WAVES=6 bash cs397raytracingsp22_amd/csrc/build.sh && cp .../libmi_rt.so tmp_variants/libw6.so
+ARGS="$1"; shift
+cp cs397raytracingsp22_amd/lib/libmi_rt.so /tmp/libmi_rt_keep.so
+for rep in 1 2; do for e in "$@"; do cp "$e" cs397raytracingsp22_amd/lib/libmi_rt.so; echo "RES [$e] $(python tools/probe.py $ARGS 2>&1 | grep -a '^RES' | head -1)"; done; done
+cp /tmp/libmi_rt_keep.so cs397raytracingsp22_amd/lib/libmi_rt.so
