@@ -137,7 +137,7 @@ struct mi_ctx {
     struct Tuning {
         uint32_t vote_t = 2, vote_a = 1, k_steps = 8;   // voted megakernel
         uint32_t lds_pad = 0;                           // occupancy experiments
-        uint32_t refill_min = 32;                       // wf_trav: refill idle lanes when at least this many are idle
+        uint32_t refill_min = 16;                       // wf_trav: refill idle lanes when at least this many are idle (A/B round 2: 32 / 16 / 8 -> 36.9 / 35.8 / 38.6 ms on cfg2)
         uint32_t fuse_max = 1, fuse_min = 32;           // wf_main: in-launch continuation (rounds, lanes needed)
         int trav_lds = -1;                              // wf_trav LDS mode override (-1 = automatic)
         int trav_bpc = 0;                               // wf_trav blocks per CU override (0 = automatic)

@@ -36,7 +36,7 @@
 #pragma clang fp contract(off)
 
 #ifndef PT_MAIN_WAVES
-#define PT_MAIN_WAVES 4     // wf_main: minimum waves per SIMD the register allocator must allow
+#define PT_MAIN_WAVES 6     // wf_main: waves per SIMD the register allocator must allow (A/B round 2: 4 -> 90 VGPRs 99.5 ms, 6 -> 80 VGPRs 97.4 ms on cfg2)
 #endif
 #ifndef PT_TRAV_BURST
 #define PT_TRAV_BURST 6     // wf_trav: interior steps per vote (sweep: 2/4/6/8 -> 52.6/46.8/45.8/46.3 ms at refill 32;
@@ -1535,6 +1535,13 @@ __global__ __launch_bounds__(kBlock, PT_MAIN_WAVES) void wf_main(WfArgs A) {
 #endif
 }
 
+// Which shard's queue region holds virtual index v of the concatenated traversal queue: wave-uniform v, scalar loads.
+__device__ __forceinline__ uint32_t wf_shard_of(const PT_CONST_AS uint32_t* pfx, uint32_t v) {
+    uint32_t lo = 0, hi = (uint32_t)kWfShards;
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (pfx[mid] <= v) lo = mid; else hi = mid; }
+    return lo;
+}
+
 // persistent BVH walker with per-lane dynamic refill from the sharded queues
 // LDS: 0 = BVH in global memory, 1 = nodes + triangles in LDS, 2 = nodes in LDS, triangles in global
 template <int LDS> struct TravBvh { typedef Bvh<false> type; };
@@ -1577,6 +1584,9 @@ __global__ __launch_bounds__(BS, (BS == 256 ? PT_TRAV_WAVES : 4)) void wf_trav(W
     uint32_t wnext = wave_id * chunk, wend = min(wnext + chunk, n_q);
     bool drained = false;
     if (wnext >= n_q) { wnext = wend = 0; drained = true; }
+    // shard of the chunk's first entry, kept wave-uniform (SGPRs): a lane then finds its own shard with a step or two
+    // instead of an eight-deep chain of dependent vector loads at every refill
+    uint32_t wlo = drained ? 0u : wf_shard_of(A.trav_pfx, (uint32_t)__builtin_amdgcn_readfirstlane((int)wnext));
     bool have = false;
     size_t pos = 0;
     f3 o = mk3(0.0f, 0.0f, 0.0f), d = o, too = o, tod = o, tinv = o;
@@ -1598,15 +1608,15 @@ __global__ __launch_bounds__(BS, (BS == 256 ? PT_TRAV_WAVES : 4)) void wf_trav(W
                     base = (uint32_t)__shfl((int)base, 0);
                 }
                 if (base >= n_q) drained = true;
-                else { wnext = base; wend = min(base + chunk, n_q); }
+                else { wnext = base; wend = min(base + chunk, n_q); wlo = wf_shard_of(A.trav_pfx, (uint32_t)__builtin_amdgcn_readfirstlane((int)base)); }
             }
             const uint32_t avail = wend - wnext;
             const uint32_t rank = (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
             const bool take = !have && rank < avail;
             if (take) {
                 const uint32_t vi = wnext + rank;
-                uint32_t lo = 0, hi = (uint32_t)kWfShards;          // which shard's region holds virtual index vi
-                while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (A.trav_pfx[mid] <= vi) lo = mid; else hi = mid; }
+                uint32_t lo = wlo;                                   // which shard's region holds virtual index vi (>= the chunk's first)
+                while (A.trav_pfx[lo + 1] <= vi) lo++;               // trav_pfx[kWfShards] = n_q > vi
                 pos = A.trav_q[(size_t)lo * A.region + (vi - A.trav_pfx[lo])];
                 const float4 q0 = A.st_out[st_idx(0, pos, cap)], q1 = A.st_out[st_idx(1, pos, cap)];
                 const Hit2 hr = *st_hit(A.st_out, pos, cap);
@@ -1622,6 +1632,7 @@ __global__ __launch_bounds__(BS, (BS == 256 ? PT_TRAV_WAVES : 4)) void wf_trav(W
                 }
             }
             wnext += min(avail, n_idle);
+            if (wnext < wend) { const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)wnext); while (A.trav_pfx[wlo + 1] <= w) wlo++; }
         }
         if (__builtin_amdgcn_ballot_w64(have) == 0ull) {
             if (drained) break;
@@ -1629,6 +1640,11 @@ __global__ __launch_bounds__(BS, (BS == 256 ? PT_TRAV_WAVES : 4)) void wf_trav(W
         }
 
         // ---- one voted step: a burst of interior nodes or one leaf (same code as the voted K1) ----
+        // (Negative result, round 2: DEFERRING the leaves — a lane notes up to three leaves and walks on as if their
+        // triangle tests had failed, the noted tests run together later, and a test that passes throws the speculation
+        // away and resumes at that leaf's successor with the new bound — is exact (all 153 GPU tests green) but slower:
+        // wf_trav 35.6 -> 43.5 ms on cfg2, 81 -> 96 ms on cfg4: 74 instead of 64 VGPRs (6 instead of 8 waves per SIMD),
+        // 20 % more instructions per node step, and every hit replays part of the walk.)
         const int tri = __float_as_int(c1.w);
         const bool at_leaf = have & (tri >= 0), at_inner = have & (tri < 0);
         const int n_leaf = __popcll(__builtin_amdgcn_ballot_w64(at_leaf));
@@ -1772,6 +1788,9 @@ __global__ __launch_bounds__(256, PT_TRAV_WAVES) void wf_trav_f(WfArgs A) {
     uint32_t wnext = wave_id * chunk, wend = min(wnext + chunk, n_q);
     bool drained = false;
     if (wnext >= n_q) { wnext = wend = 0; drained = true; }
+    // shard of the chunk's first entry, kept wave-uniform (SGPRs): a lane then finds its own shard with a step or two
+    // instead of an eight-deep chain of dependent vector loads at every refill
+    uint32_t wlo = drained ? 0u : wf_shard_of(A.trav_pfx, (uint32_t)__builtin_amdgcn_readfirstlane((int)wnext));
 
     bool have = false, atleaf = false;
     uint32_t vi = 0, pos = 0, nc = 0, fb = 0;
@@ -1793,15 +1812,15 @@ __global__ __launch_bounds__(256, PT_TRAV_WAVES) void wf_trav_f(WfArgs A) {
                     base = (uint32_t)__shfl((int)base, 0);
                 }
                 if (base >= n_q) drained = true;
-                else { wnext = base; wend = min(base + chunk, n_q); }
+                else { wnext = base; wend = min(base + chunk, n_q); wlo = wf_shard_of(A.trav_pfx, (uint32_t)__builtin_amdgcn_readfirstlane((int)base)); }
             }
             const uint32_t avail = wend - wnext;
             const uint32_t rank = (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
             const bool take = !have && rank < avail;
             if (take) {
                 vi = wnext + rank;
-                uint32_t lo = 0, hi = (uint32_t)kWfShards;
-                while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (A.trav_pfx[mid] <= vi) lo = mid; else hi = mid; }
+                uint32_t lo = wlo;
+                while (A.trav_pfx[lo + 1] <= vi) lo++;
                 pos = A.trav_q[(size_t)lo * A.region + (vi - A.trav_pfx[lo])];
                 const float4 q0 = A.st_out[st_idx(0, pos, cap)], q1 = A.st_out[st_idx(1, pos, cap)];
                 const f3 o = mk3(q0.x, q0.y, q0.z), d = mk3(q0.w, q1.x, q1.y);
@@ -1814,6 +1833,7 @@ __global__ __launch_bounds__(256, PT_TRAV_WAVES) void wf_trav_f(WfArgs A) {
                 }
             }
             wnext += min(avail, n_idle);
+            if (wnext < wend) { const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)wnext); while (A.trav_pfx[wlo + 1] <= w) wlo++; }
         }
         if (__builtin_amdgcn_ballot_w64(have) == 0ull) {
             if (drained) break;
