@@ -98,7 +98,7 @@ struct mi_ctx {
     uint32_t lds_bytes = 0;                  // bytes needed to stage nodes + tris, 0 = no meshes
     // per live mesh (Scene.objects order): end of its nodes in the node pool, does the two-stage bound apply to it at all,
     // is it walked two-stage by default (qualifies and large enough for the F-tree to pay)
-    std::vector<int> mesh_node_end; std::vector<uint8_t> mesh_qualifies, mesh_default_ts;
+    std::vector<int> mesh_node_end, mesh_e2_end; std::vector<uint8_t> mesh_qualifies, mesh_default_ts;
     void* d_cand = nullptr; size_t cand_bytes = 0;           // two-stage candidates [cap][kCandMax] {t, key}
     void* d_cand_hdr = nullptr; size_t cand_hdr_bytes = 0;   // [cap] {pos, count | flags}
 
@@ -272,7 +272,7 @@ extern "C" int mi_scene_upload(mi_ctx* c, const mi_scene_desc* d) {
     std::vector<DMeshF> meshf((size_t)d->n_meshes);
     struct MeshBuild { std::vector<float> nodes, fnodes, ftris; bool qualifies = false, default_ts = false; };
     std::vector<MeshBuild> mb((size_t)d->n_meshes);
-    std::vector<float> nodes, tris, fnodes, ftris;
+    std::vector<float> nodes, tris, fnodes, ftris, e2s;
     std::vector<DTriAttr> attrs;
     std::vector<DTexture> texs((size_t)d->n_textures);
     std::vector<uint8_t> texels;
@@ -377,6 +377,20 @@ extern "C" int mi_scene_upload(mi_ctx* c, const mi_scene_desc* d) {
             const int nbase = (int)(nodes.size() / 8), fbase = (int)(fnodes.size() / 8);
             M.node_begin = nbase;
             for (size_t k = 0; k < B.nodes.size(); k += 8) { int sk; memcpy(&sk, &B.nodes[k + 3], 4); sk += nbase; memcpy(&B.nodes[k + 3], &sk, 4); }
+            // leaf nodes carry {a, skip}{e1, tri} instead of their (never tested) box; e2 goes to its own small pool
+            M.e2_begin = (int)(e2s.size() / 4);
+            for (size_t k = 0; k < B.nodes.size(); k += 8) {
+                int tri; memcpy(&tri, &B.nodes[k + 7], 4);
+                if (tri < 0) continue;
+                const float* T = &tris[((size_t)M.tri_begin + (size_t)tri) * 12];
+                B.nodes[k + 0] = T[0]; B.nodes[k + 1] = T[1]; B.nodes[k + 2] = T[2];
+                B.nodes[k + 4] = T[4]; B.nodes[k + 5] = T[5]; B.nodes[k + 6] = T[6];
+            }
+            for (int t = 0; t < M.n_tris; t++) {
+                const float* T = &tris[((size_t)M.tri_begin + (size_t)t) * 12];
+                const float rec[4] = { T[8], T[9], T[10], 0.0f };
+                e2s.insert(e2s.end(), rec, rec + 4);
+            }
             nodes.insert(nodes.end(), B.nodes.begin(), B.nodes.end());
             M.node_end = (int)(nodes.size() / 8);
             for (size_t k = 0; k < B.fnodes.size(); k += 8) { int sk; memcpy(&sk, &B.fnodes[k + 3], 4); sk += fbase; memcpy(&B.fnodes[k + 3], &sk, 4); }
@@ -451,12 +465,13 @@ extern "C" int mi_scene_upload(mi_ctx* c, const mi_scene_desc* d) {
     // meshes that are not referenced by Scene.objects are not part of the scene
     std::vector<DMesh> live;
     std::vector<DMeshF> livef;
-    c->mesh_node_end.clear(); c->mesh_qualifies.clear(); c->mesh_default_ts.clear();
+    c->mesh_node_end.clear(); c->mesh_e2_end.clear(); c->mesh_qualifies.clear(); c->mesh_default_ts.clear();
     for (int i = 0; i < d->n_objects; i++)
         if (objs[(size_t)i].kind == OBJ_MESH) {
             int r = objs[(size_t)i].ref; objs[(size_t)i].ref = (int)live.size();
             live.push_back(meshes[(size_t)r]); livef.push_back(meshf[(size_t)r]);
             c->mesh_node_end.push_back(meshes[(size_t)r].node_end);
+            c->mesh_e2_end.push_back(meshes[(size_t)r].e2_begin + meshes[(size_t)r].n_tris);
             c->mesh_qualifies.push_back(mb[(size_t)r].qualifies ? 1 : 0); c->mesh_default_ts.push_back(mb[(size_t)r].default_ts ? 1 : 0);
         }
 
@@ -513,7 +528,8 @@ extern "C" int mi_scene_upload(mi_ctx* c, const mi_scene_desc* d) {
     size_t off_fnodes = align(off_meshf + livef.size() * sizeof(DMeshF));
     size_t off_ftris = align(off_fnodes + fnodes.size() * 4 + 32);
     size_t off_nodes = align(off_ftris + ftris.size() * 4 + 48);
-    size_t off_tris = align(off_nodes + nodes.size() * 4);
+    size_t off_e2 = align(off_nodes + nodes.size() * 4);
+    size_t off_tris = align(off_e2 + e2s.size() * 4 + 16);
     size_t off_attr = align(off_tris + tris.size() * 4);
     size_t off_tex = align(off_attr + attrs.size() * sizeof(DTriAttr));
     size_t off_texel = align(off_tex + texs.size() * sizeof(DTexture));
@@ -529,6 +545,7 @@ extern "C" int mi_scene_upload(mi_ctx* c, const mi_scene_desc* d) {
     put(off_fnodes, fnodes.data(), fnodes.size() * 4);
     put(off_ftris, ftris.data(), ftris.size() * 4);
     put(off_nodes, nodes.data(), nodes.size() * 4);
+    put(off_e2, e2s.data(), e2s.size() * 4);
     put(off_tris, tris.data(), tris.size() * 4);
     put(off_attr, attrs.data(), attrs.size() * sizeof(DTriAttr));
     put(off_tex, texs.data(), texs.size() * sizeof(DTexture));
@@ -551,6 +568,7 @@ extern "C" int mi_scene_upload(mi_ctx* c, const mi_scene_desc* d) {
     c->S.ftris = (const float*)(b + off_ftris);
     c->S.n_fnodes = (int)(fnodes.size() / 8);
     c->S.nodes = (const float*)(b + off_nodes);
+    c->S.e2s = (const float*)(b + off_e2);
     c->S.tris = (const float*)(b + off_tris);
     c->S.triattr = (const DTriAttr*)(b + off_attr);
     c->S.textures = (const DTexture*)(b + off_tex);
@@ -905,19 +923,22 @@ static int render_tiles_wavefront(mi_ctx* c, const K1Args& k, const mi_camera_de
     // teapot 15 KB -> 8 blocks per CU; 122.6 ms vs 126.0 ms for mode 1 on cfg2 1080p/256), 1 = nodes +
     // triangles (what the megakernels stage), 0 = everything from global memory.  The LDS window is the head of the node
     // pool up to the last tree wf_trav walks (the scene compiler places those trees first).
-    int ref_nodes = 0;
-    for (size_t m = 0; m < c->mesh_node_end.size() && m < 32; m++) if ((ref_mask >> m) & 1u) ref_nodes = std::max(ref_nodes, c->mesh_node_end[m]);
-    const size_t node_bytes = (size_t)ref_nodes * 32;
-    // 3 = nodes in LDS too, but they need most of a CU's 160 KB: ONE 1024-thread block per CU (16 waves)
+    int ref_nodes = 0, ref_e2 = 0;
+    for (size_t m = 0; m < c->mesh_node_end.size() && m < 32; m++) if ((ref_mask >> m) & 1u) {
+        ref_nodes = std::max(ref_nodes, c->mesh_node_end[m]); ref_e2 = std::max(ref_e2, c->mesh_e2_end[m]);
+    }
+    // LDS image of a walker block: the nodes (leaves carry a and e1 of their triangle) + the triangles' e2 vectors
+    const size_t node_bytes = (size_t)ref_nodes * 32 + (size_t)ref_e2 * 16;
+    // 3 = the image needs most of a CU's 160 KB: ONE 1024-thread block per CU (16 waves)
     int trav_lds_mode = 0;
     if (ref_nodes > 0 && !c->tune.global_bvh) trav_lds_mode = node_bytes <= 64u * 1024u ? 2 : (node_bytes <= 156u * 1024u ? 3 : 0);
     if (c->tune.trav_lds >= 0) {
         const int m = c->tune.trav_lds;
-        if (m == 0 || (m == 1 && lds && ref_nodes == c->S.n_nodes) || (m == 2 && node_bytes <= 64u * 1024u) || (m == 3 && node_bytes <= 156u * 1024u)) trav_lds_mode = m;
+        if (m == 0 || (m == 2 && node_bytes <= 64u * 1024u) || (m == 3 && node_bytes <= 156u * 1024u)) trav_lds_mode = m;
     }
-    const size_t trav_lds_bytes = trav_lds_mode == 1 ? c->lds_bytes : (trav_lds_mode >= 2 ? node_bytes : 0);
+    const size_t trav_lds_bytes = trav_lds_mode >= 2 ? node_bytes : 0;
     a.R.lds_nodes = trav_lds_mode ? (uint32_t)ref_nodes : 0;
-    a.R.lds_tris = trav_lds_mode == 1 ? (uint32_t)c->S.n_tris : 0;
+    a.R.lds_tris = trav_lds_mode ? (uint32_t)ref_e2 : 0;          // e2 entries staged behind the nodes
     a.cand = (uint2*)c->d_cand; a.cand_hdr = (uint2*)c->d_cand_hdr;
     float4* bufs[2] = { (float4*)c->d_wf_a, (float4*)c->d_wf_b };
     uint32_t trav_bpc = 6;                  // resident blocks per CU: bounded by LDS (160 KB) and by 8 waves/SIMD

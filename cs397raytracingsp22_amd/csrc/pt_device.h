@@ -10,7 +10,7 @@
 //    subtree.  The reference always descends left-then-right (geometry.rs:105-115),
 //    so a skip link replaces the traversal stack exactly.
 //  * Nodes are 2 x float4 (32 B), triangles 3 x float4 (a, e1, e2 — 48 B) so a lane
-//    fetches a node / triangle with 16-byte loads from LDS or L1/L2.
+//    fetches a node / triangle with 16-byte loads from LDS or L1/L2.  Leaf nodes hold {a, skip}{e1, tri} (see DScene.e2s).
 //  * Per-triangle shading attributes (normals, uvs, tangent) are a separate array
 //    touched once per mesh HIT, not per candidate.
 #pragma once
@@ -85,7 +85,7 @@ struct alignas(16) DMesh {
     int32_t  material;           // -1 = ParameterizedMaterial from textures
     int32_t  tex[5];             // -1 = None
     int32_t  object_index;       // position in Scene.objects (tie-breaking)
-    int32_t  pad;
+    int32_t  e2_begin;           // first entry of this mesh in the e2 pool (leaf-embedded triangles, see DScene.e2s)
 };
 static_assert(sizeof(DMesh) % 16 == 0, "DMesh must be 16-byte sized");
 
@@ -117,6 +117,11 @@ struct DScene {
     const PT_CONST_AS DMesh*     meshes;
     const PT_CONST_AS float*     nodes;      // float4 pairs: {bmin.xyz, skip(int)} {bmax.xyz, tri(int, -1 = interior)}
     const PT_CONST_AS float*     tris;       // float4 triples: {a.xyz, 0} {e1.xyz, 0} {e2.xyz, 0}
+    // LEAF nodes carry their triangle instead of a box (the reference never box-tests a leaf, geometry.rs:95, so no
+    // kernel reads a leaf's box): {a.xyz, skip}{e1.xyz, tri}; the third operand comes from this pool, float4 {e2.xyz, 0} per
+    // triangle, ordered like the node pool.  A walker that has just fetched a leaf node from LDS then needs ONE more
+    // 16-byte LDS read for the triangle test — no trip to global memory inside the walk.
+    const PT_CONST_AS float*     e2s;
     const PT_CONST_AS DTriAttr*  triattr;
     const PT_CONST_AS DTexture*  textures;
     const PT_CONST_AS uint8_t*   texels;

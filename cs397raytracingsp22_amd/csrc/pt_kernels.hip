@@ -42,6 +42,9 @@
 #define PT_TRAV_BURST 6     // wf_trav: interior steps per vote (sweep: 2/4/6/8 -> 52.6/46.8/45.8/46.3 ms at refill 32;
                             // leaving a burst early when < 16/24/32 lanes are still on interior nodes: +1/+2/+5 ms)
 #endif
+#ifndef PT_TRAV_LEAF_W
+#define PT_TRAV_LEAF_W 2    // wf_trav: a leaf step is taken when n_leaf * W > n_inner (A/B round 2, leaves in LDS: W = 1 / 2 -> 33.2 / 30.8 ms on cfg2)
+#endif
 #ifndef PT_TRAV_WAVES
 #define PT_TRAV_WAVES 6     // wf_trav: waves per SIMD (LDS admits 6 blocks of 26.8 KB per CU)
 #endif
@@ -1543,9 +1546,8 @@ __device__ __forceinline__ uint32_t wf_shard_of(const PT_CONST_AS uint32_t* pfx,
 }
 
 // persistent BVH walker with per-lane dynamic refill from the sharded queues
-// LDS: 0 = BVH in global memory, 1 = nodes + triangles in LDS, 2 = nodes in LDS, triangles in global
+// LDS: 0 = BVH in global memory, 2 = nodes (leaves carry a and e1 of their triangle) + the e2 vectors in LDS
 template <int LDS> struct TravBvh { typedef Bvh<false> type; };
-template <> struct TravBvh<1> { typedef Bvh<true> type; };
 template <> struct TravBvh<2> { typedef BvhNodesLds type; };
 __device__ __forceinline__ void bvh_bind(BvhNodesLds& B, const DScene& S, int) { B.nodes = k1_lds; B.tris = (cf4_ptr)S.tris; }
 
@@ -1565,15 +1567,16 @@ __global__ __launch_bounds__(BS, (BS == 256 ? PT_TRAV_WAVES : 4)) void wf_trav(W
     const bool shared_part = n_waves * chunk < n_q;                  // anything beyond the static chunks?
     if (blockIdx.x * ((uint32_t)BS / 64u) * chunk >= n_q) return;       // nothing for this block (then nothing is left over either)
     typename TravBvh<LDS>::type B;
+    const int lds_nn = (int)A.R.lds_nodes * 2;                       // float4 slots of the staged nodes; the e2 vectors follow
     if (LDS != 0) {
         cf4_ptr gn = (cf4_ptr)S.nodes;
-        cf4_ptr gt = (cf4_ptr)S.tris;
-        int nn = (int)A.R.lds_nodes * 2, nt = (LDS == 1) ? (int)A.R.lds_tris * 3 : 0;
-        for (int k = threadIdx.x; k < nn; k += BS) k1_lds[k] = gn[k];
-        for (int k = threadIdx.x; k < nt; k += BS) k1_lds[nn + k] = gt[k];
+        cf4_ptr ge = (cf4_ptr)S.e2s;
+        const int ne = (int)A.R.lds_tris;
+        for (int k = threadIdx.x; k < lds_nn; k += BS) k1_lds[k] = gn[k];
+        for (int k = threadIdx.x; k < ne; k += BS) k1_lds[lds_nn + k] = ge[k];
         __syncthreads();
     }
-    bvh_bind(B, S, (int)A.R.lds_nodes * 2);
+    bvh_bind(B, S, lds_nn);
     const float t_min = 0.001f, t_max = A.C.max_trace_dist;
     const uint32_t cap = A.cap;
     const int last_node = S.n_nodes - 1;
@@ -1591,9 +1594,13 @@ __global__ __launch_bounds__(BS, (BS == 256 ? PT_TRAV_WAVES : 4)) void wf_trav(W
     size_t pos = 0;
     f3 o = mk3(0.0f, 0.0f, 0.0f), d = o, too = o, tod = o, tinv = o;
     Best best; best.t = 0.0f; best.obj = -1; best.tri = -1; best.u = best.v = 0.0f;
-    int tm = 0, ti = 0, tend = 0, ttb = 0, tbtri = -1;
+    int tm = 0, ti = 0, tend = 0, ttb = 0, te2 = 0, tbtri = -1;
     float tbt = 0.0f, tbu = 0.0f, tbv = 0.0f;
     float4 c0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), c1 = c0;
+#ifdef PT_TRAV_DIAG
+    // developer build: where do the lanes go?  (wave-uniform counters, summed into A.diag at exit)
+    unsigned long long dg_trips = 0, dg_bsteps = 0, dg_blanes = 0, dg_lsteps = 0, dg_llanes = 0, dg_refills = 0, dg_rlanes = 0, dg_have = 0;
+#endif
 
     while (true) {
         // ---- refill idle lanes ----
@@ -1627,17 +1634,24 @@ __global__ __launch_bounds__(BS, (BS == 256 ? PT_TRAV_WAVES : 4)) void wf_trav(W
                 tm = 0;
                 if (enter_next_mesh(S, B, tm, o, d, t_min, t_max, too, tod, tinv, ti, tend, ttb, A.trav_mask)) {
                     tbt = t_max; tbtri = -1; tbu = tbv = 0.0f;
+                    te2 = S.meshes[tm].e2_begin;
                     B.node(ti, c0, c1);
                     have = true;
                 }
             }
             wnext += min(avail, n_idle);
             if (wnext < wend) { const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)wnext); while (A.trav_pfx[wlo + 1] <= w) wlo++; }
+#ifdef PT_TRAV_DIAG
+            dg_refills++; dg_rlanes += (unsigned long long)__popcll(__builtin_amdgcn_ballot_w64(take));
+#endif
         }
         if (__builtin_amdgcn_ballot_w64(have) == 0ull) {
             if (drained) break;
             continue;
         }
+#ifdef PT_TRAV_DIAG
+        dg_trips++; dg_have += (unsigned long long)__popcll(__builtin_amdgcn_ballot_w64(have));
+#endif
 
         // ---- one voted step: a burst of interior nodes or one leaf (same code as the voted K1) ----
         // (Negative result, round 2: DEFERRING the leaves — a lane notes up to three leaves and walks on as if their
@@ -1649,32 +1663,41 @@ __global__ __launch_bounds__(BS, (BS == 256 ? PT_TRAV_WAVES : 4)) void wf_trav(W
         const bool at_leaf = have & (tri >= 0), at_inner = have & (tri < 0);
         const int n_leaf = __popcll(__builtin_amdgcn_ballot_w64(at_leaf));
         const int n_inner = __popcll(__builtin_amdgcn_ballot_w64(at_inner));
-        if (n_inner >= n_leaf) {
+        if (n_inner >= n_leaf * PT_TRAV_LEAF_W) {
             // burst of interior steps, no vote in between.  At 6 waves/SIMD the LDS latency of the
             // dependent node fetch is covered by the other waves, and this form is 20 instructions
             // per step shorter than prefetching both successors and selecting (used in K1).
 #pragma unroll
             for (int j = 0; j < PT_TRAV_BURST; j++) {
                 const bool act = have & (ti < tend) & (__float_as_int(c1.w) < 0);
+#ifdef PT_TRAV_DIAG
+                dg_bsteps++; dg_blanes += (unsigned long long)__popcll(__builtin_amdgcn_ballot_w64(act));
+#endif
                 const bool hit = slab(mk3(c0.x, c0.y, c0.z), mk3(c1.x, c1.y, c1.z), too, tinv, t_min, tbt);
                 const int nxt = hit ? ti + 1 : __float_as_int(c0.w);
                 ti = act ? nxt : ti;
                 if (act) B.node(min(ti, last_node), c0, c1);
             }
         } else if (at_leaf) {
-            f3 a, e1, e2;
-            B.tri(ttb + tri, a, e1, e2);
+            // the leaf node just fetched IS the triangle's a and e1 (pt_device.h DScene.e2s); e2 is one more 16-byte read
+            // from the LDS image (or from the e2 pool when the tree is walked from global memory)
+            float4 ev;
+            if (LDS != 0) ev = k1_lds[lds_nn + te2 + tri]; else ev = ((cf4_ptr)S.e2s)[te2 + tri];
             float t, u, v;
-            bool ok = tri_t(too, tod, a, e1, e2, t_min, tbt, t, u, v);
+            bool ok = tri_t(too, tod, mk3(c0.x, c0.y, c0.z), mk3(c1.x, c1.y, c1.z), mk3(ev.x, ev.y, ev.z), t_min, tbt, t, u, v);
             tbt = ok ? t : tbt; tbtri = ok ? tri : tbtri; tbu = ok ? u : tbu; tbv = ok ? v : tbv;
             ti = ti + 1;
             B.node(min(ti, last_node), c0, c1);
         }
+#ifdef PT_TRAV_DIAG
+        if (n_inner < n_leaf) { dg_lsteps++; dg_llanes += (unsigned long long)n_leaf; }
+#endif
         if (have && ti >= tend) {
             if (tbtri >= 0) consider(best, tbt, S.meshes[tm].object_index, tbtri, tbu, tbv);
             tm++;
             if (enter_next_mesh(S, B, tm, o, d, t_min, t_max, too, tod, tinv, ti, tend, ttb, A.trav_mask)) {
                 tbt = t_max; tbtri = -1; tbu = tbv = 0.0f;
+                te2 = S.meshes[tm].e2_begin;
                 B.node(ti, c0, c1);
             } else {
                 // StaticMesh results merged: hand the closest hit back to the path.  70 % of the rays that enter
@@ -1689,6 +1712,12 @@ __global__ __launch_bounds__(BS, (BS == 256 ? PT_TRAV_WAVES : 4)) void wf_trav(W
             }
         }
     }
+#ifdef PT_TRAV_DIAG
+    if (A.diag && lane == 0) {
+        atomicAdd(&A.diag[0], dg_trips); atomicAdd(&A.diag[1], dg_have); atomicAdd(&A.diag[2], dg_bsteps); atomicAdd(&A.diag[3], dg_blanes);
+        atomicAdd(&A.diag[4], dg_lsteps); atomicAdd(&A.diag[5], dg_llanes); atomicAdd(&A.diag[6], dg_refills); atomicAdd(&A.diag[7], dg_rlanes);
+    }
+#endif
 }
 
 // ---------------------------------------------------------------- exact two-stage mesh traversal
@@ -1896,10 +1925,35 @@ __global__ __launch_bounds__(256) void wf_replay(WfArgs A) {
     cf4_ptr RN = (cf4_ptr)S.nodes;
     Bvh<false> B;
     bvh_bind(B, S, 0);
-    for (uint32_t vi = blockIdx.x * blockDim.x + threadIdx.x; vi < n_q; vi += gridDim.x * blockDim.x) {
+    // Most queued rays have no candidate at all (they entered a root box and passed no triangle): with one thread per
+    // queue entry 9.5 of 64 lanes did any work (PMC, HEAD scene).  So every wave COMPACTS first: it scans the headers 64 at
+    // a time, collects the entries that need a replay in a small LDS queue of its own (ballot + prefix count, no atomics),
+    // and runs the replay body only on full batches of 64.
+    __shared__ volatile uint32_t rq[4][128];
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const uint32_t n_waves = gridDim.x * 4u;
+    uint32_t scan = (blockIdx.x * 4u + wv) * 64u;        // wave-uniform cursor over the queue, strided by the waves
+    uint32_t qn = 0;                                       // entries waiting in this wave's LDS queue (wave-uniform)
+    for (;;) {
+        while (qn < 64u && scan < n_q) {
+            const uint32_t e = scan + lane;
+            const bool want = e < n_q && A.cand_hdr[e].y != 0u;
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(want);
+            if (want) rq[wv][qn + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = e;
+            qn += (uint32_t)__popcll(m);
+            scan += n_waves * 64u;
+        }
+        if (qn == 0u) break;
+        const uint32_t take = qn < 64u ? qn : 64u;
+        const bool active = lane < take;
+        const uint32_t vi = active ? rq[wv][lane] : 0u;
+        const uint32_t moved = (lane < qn - take) ? rq[wv][64u + lane] : 0u;      // the rest moves to the front of the queue
+        __builtin_amdgcn_wave_barrier();
+        if (lane < qn - take) rq[wv][lane] = moved;
+        qn -= take;
+        if (active) {
         const uint2 hdr = A.cand_hdr[vi];
         const uint32_t nc = hdr.y & 0xffu, fb = hdr.y >> 8;
-        if (nc == 0u && fb == 0u) continue;
         const size_t pos = hdr.x;
         const float4 q0 = A.st_out[st_idx(0, pos, cap)], q1 = A.st_out[st_idx(1, pos, cap)];
         const f3 o = mk3(q0.x, q0.y, q0.z), d = mk3(q0.w, q1.x, q1.y);
@@ -1995,6 +2049,7 @@ __global__ __launch_bounds__(256) void wf_replay(WfArgs A) {
             *st_tri(A.st_out, pos, cap) = best.tri;
             A.st_out[st_idx(5, pos, cap)] = make_float4(u, v, 0.0f, 0.0f);
         }
+        }   // active
     }
 }
 
@@ -2173,7 +2228,6 @@ hipError_t launch_wf_trav(const WfArgs& a, uint32_t n_blocks, int lds_mode, size
         }
         hipLaunchKernelGGL((wf_trav<2, 1024>), grid, dim3(1024), lds_bytes, stream, a);
     }
-    else if (lds_mode == 1) hipLaunchKernelGGL((wf_trav<1, 256>), grid, block, lds_bytes, stream, a);
     else if (lds_mode == 2) hipLaunchKernelGGL((wf_trav<2, 256>), grid, block, lds_bytes, stream, a);
     else hipLaunchKernelGGL((wf_trav<0, 256>), grid, block, 0, stream, a);
     return hipGetLastError();

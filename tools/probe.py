@@ -63,6 +63,10 @@ def main():
                 best = (st.kernel_ms, ctx.last_pipeline_ms(), ctx.last_pipeline_counts(), st.samples)
         print(f"RES {tag}: {best[0]:.2f} ms, {best[3] / best[0] / 1e3:.0f} Msamples/s",
               {k: round(v, 2) for k, v in best[1].items()}, best[2], flush=True)
+        if os.environ.get("MI_RT_WF_STAMPS"):
+            out = (__import__("ctypes").c_uint64 * 16)()
+            abi.check(ctx._lib.mi_last_diag(ctx._h, out))
+            print("RES diag", [int(v) for v in out][:8], flush=True)
         if a.check:
             _, _, s0, _ = ctx.render(cam, want_u8=False, want_sig=True, variant=a.variant, flags=a.flags)
             for name, fl in (("reference-walk", abi.MI_OPT_REFERENCE_WALK), ("no-tile-masks", abi.MI_OPT_NO_TILE_MASKS),
