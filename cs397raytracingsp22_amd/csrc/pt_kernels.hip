@@ -39,11 +39,22 @@
 #define PT_MAIN_WAVES 6     // wf_main: waves per SIMD the register allocator must allow (A/B round 2: 4 -> 90 VGPRs 99.5 ms, 6 -> 80 VGPRs 97.4 ms on cfg2)
 #endif
 #ifndef PT_TRAV_BURST
-#define PT_TRAV_BURST 6     // wf_trav: interior steps per vote (sweep: 2/4/6/8 -> 52.6/46.8/45.8/46.3 ms at refill 32;
-                            // leaving a burst early when < 16/24/32 lanes are still on interior nodes: +1/+2/+5 ms)
+#define PT_TRAV_BURST 10    // wf_trav / wf_trav_f: interior steps per vote.  Round 1 (triangles fetched from global memory in the leaf
+                            // step): 2/4/6/8 -> 52.6/46.8/45.8/46.3 ms.  Round 2 (leaves in the LDS image): 6/8/10/12/16 -> 30.7/29.6/28.6/29.4/31.0 ms
+                            // on cfg2; leaving a burst early when < 24/32 lanes are still on interior nodes: +3/+7 ms
+#endif
+#ifndef PT_TRAVF_BURST
+#define PT_TRAVF_BURST 6    // wf_trav_f: F-node steps per vote
 #endif
 #ifndef PT_TRAV_LEAF_W
-#define PT_TRAV_LEAF_W 2    // wf_trav: a leaf step is taken when n_leaf * W > n_inner (A/B round 2, leaves in LDS: W = 1 / 2 -> 33.2 / 30.8 ms on cfg2)
+#define PT_TRAV_LEAF_W 3    // wf_trav: a leaf step is taken when n_leaf * W > n_inner (leaves in LDS: W = 1/2/3/4 -> 33.2/30.8/30.6/30.6 ms on cfg2)
+#endif
+#ifndef PT_TRAV_DYN
+#define PT_TRAV_DYN 0       // wf_trav: leave a burst early when fewer than this many lanes are still on interior nodes (0 = never; see above)
+#endif
+#ifndef PT_TRAV_LEAF2
+#define PT_TRAV_LEAF2 16    // wf_trav: a leaf step tests a second triangle when at least this many lanes sit on a leaf again (the reference's
+                            // tree ends in pairs of sibling leaves): 29.4 -> 28.5 ms on cfg2, 71.7 -> 69.9 on cfg4 (0 = never)
 #endif
 #ifndef PT_TRAV_WAVES
 #define PT_TRAV_WAVES 6     // wf_trav: waves per SIMD (LDS admits 6 blocks of 26.8 KB per CU)
@@ -1677,17 +1688,26 @@ __global__ __launch_bounds__(BS, (BS == 256 ? PT_TRAV_WAVES : 4)) void wf_trav(W
                 const int nxt = hit ? ti + 1 : __float_as_int(c0.w);
                 ti = act ? nxt : ti;
                 if (act) B.node(min(ti, last_node), c0, c1);
+                if (PT_TRAV_DYN > 0 && j + 1 < PT_TRAV_BURST &&
+                    __popcll(__builtin_amdgcn_ballot_w64(have & (ti < tend) & (__float_as_int(c1.w) < 0))) < PT_TRAV_DYN) break;
             }
-        } else if (at_leaf) {
+        } else {
             // the leaf node just fetched IS the triangle's a and e1 (pt_device.h DScene.e2s); e2 is one more 16-byte read
             // from the LDS image (or from the e2 pool when the tree is walked from global memory)
-            float4 ev;
-            if (LDS != 0) ev = k1_lds[lds_nn + te2 + tri]; else ev = ((cf4_ptr)S.e2s)[te2 + tri];
-            float t, u, v;
-            bool ok = tri_t(too, tod, mk3(c0.x, c0.y, c0.z), mk3(c1.x, c1.y, c1.z), mk3(ev.x, ev.y, ev.z), t_min, tbt, t, u, v);
-            tbt = ok ? t : tbt; tbtri = ok ? tri : tbtri; tbu = ok ? u : tbu; tbv = ok ? v : tbv;
-            ti = ti + 1;
-            B.node(min(ti, last_node), c0, c1);
+            for (int k = 0; k < (PT_TRAV_LEAF2 > 0 ? 2 : 1); k++) {
+                const int ltri = __float_as_int(c1.w);
+                const bool lf = have & (ti < tend) & (ltri >= 0);
+                if (k > 0 && __popcll(__builtin_amdgcn_ballot_w64(lf)) < PT_TRAV_LEAF2) break;
+                if (lf) {
+                    float4 ev;
+                    if (LDS != 0) ev = k1_lds[lds_nn + te2 + ltri]; else ev = ((cf4_ptr)S.e2s)[te2 + ltri];
+                    float t, u, v;
+                    bool ok = tri_t(too, tod, mk3(c0.x, c0.y, c0.z), mk3(c1.x, c1.y, c1.z), mk3(ev.x, ev.y, ev.z), t_min, tbt, t, u, v);
+                    tbt = ok ? t : tbt; tbtri = ok ? ltri : tbtri; tbu = ok ? u : tbu; tbv = ok ? v : tbv;
+                    ti = ti + 1;
+                    B.node(min(ti, last_node), c0, c1);
+                }
+            }
         }
 #ifdef PT_TRAV_DIAG
         if (n_inner < n_leaf) { dg_lsteps++; dg_llanes += (unsigned long long)n_leaf; }
@@ -1875,7 +1895,7 @@ __global__ __launch_bounds__(256, PT_TRAV_WAVES) void wf_trav_f(WfArgs A) {
         const int n_walk = __popcll(__builtin_amdgcn_ballot_w64(walking));
         if (n_walk >= n_leaf) {
 #pragma unroll
-            for (int j = 0; j < PT_TRAV_BURST; j++) {
+            for (int j = 0; j < PT_TRAVF_BURST; j++) {
                 const bool act = have & !atleaf & (fi < fend);
                 const bool hit = slab_padded(mk3(c0.x, c0.y, c0.z), mk3(c1.x, c1.y, c1.z), op, om, tinv, t_lo, t_hi);
                 const bool leaf = __float_as_int(c1.w) >= 0;
