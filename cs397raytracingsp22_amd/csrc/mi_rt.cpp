@@ -324,6 +324,33 @@ extern "C" int mi_scene_upload(mi_ctx* c, const mi_scene_desc* d) {
             M.tex[k] = s.textures[k] < 0 ? -1 : s.textures[k];
         }
         M.object_index = -1;
+        M.tex_comb = -1;
+        if (s.material < 0) {
+            // interleaved copy of this mesh's maps (pt_device.h DMesh.tex_comb) when every bound map has the same size
+            int w = 0, h = 0, bound = 0; bool same = true;
+            for (int k = 0; k < 5; k++) if (s.textures[k] >= 0) {
+                const mi_texture& t = d->textures[s.textures[k]];
+                if (bound == 0) { w = t.width; h = t.height; } else if (t.width != w || t.height != h) same = false;
+                bound++;
+            }
+            if (bound >= 2 && same && (uint64_t)w * (uint64_t)h * 16u < (1ull << 30)) {
+                while (texels.size() % 16) texels.push_back(0);
+                DTexture T; T.offset = (uint32_t)texels.size(); T.width = w; T.height = h; T.pad = 0;
+                const size_t np = (size_t)w * h, at = texels.size();
+                texels.resize(at + np * 16, 0);
+                const uint8_t* src[5];
+                for (int k = 0; k < 5; k++) src[k] = s.textures[k] >= 0 ? d->textures[s.textures[k]].rgb : nullptr;
+                for (size_t px = 0; px < np; px++) {
+                    uint8_t* o = &texels[at + px * 16];
+                    // absent maps: albedo 0, emission 0, metallic 0, roughness 1.0 = 255 / 255 (geometry.rs:260-263)
+                    for (int ch = 0; ch < 3; ch++) { o[ch] = src[0] ? src[0][px * 3 + ch] : 0; o[4 + ch] = src[1] ? src[1][px * 3 + ch] : 0; o[8 + ch] = src[4] ? src[4][px * 3 + ch] : 0; }
+                    o[3] = src[2] ? src[2][px * 3] : 0;
+                    o[7] = src[3] ? src[3][px * 3] : 255;
+                }
+                M.tex_comb = (int)texs.size();
+                texs.push_back(T);
+            }
+        }
         M.tri_begin = (int)(tris.size() / 12);
         M.n_tris = s.n_triangles;
         MeshBuild& B = mb[(size_t)mi];

@@ -86,6 +86,12 @@ struct alignas(16) DMesh {
     int32_t  tex[5];             // -1 = None
     int32_t  object_index;       // position in Scene.objects (tie-breaking)
     int32_t  e2_begin;           // first entry of this mesh in the e2 pool (leaf-embedded triangles, see DScene.e2s)
+    // When all the maps this mesh binds have the same size, their texels are ALSO stored interleaved, 16 bytes per texel:
+    // {albedo.rgb, metallic.x}{emission.rgb, roughness.x}{normal.rgb, 0}{0}: one 16-byte fetch per hit instead of up to five
+    // 4-byte fetches from five different cache lines (incoherent rays: every fetch is a line of its own).  Same bytes, same
+    // (float)b / 255 conversions, same texel index -> same values.  -1 = not available (sizes differ / fixed material).
+    int32_t  tex_comb;           // index into DScene.textures of the interleaved array
+    int32_t  pad2[3];
 };
 static_assert(sizeof(DMesh) % 16 == 0, "DMesh must be 16-byte sized");
 

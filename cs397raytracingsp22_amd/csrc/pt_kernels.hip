@@ -473,11 +473,24 @@ __device__ __forceinline__ void resolve_hit(const DScene& S, const Best& b, f3 o
         f3 hp_obj = oo + od * b.t;                                       // tracing.rs:125
         float tu = (u * A->tb[0] + v * A->tc[0]) + w * A->ta[0];         // :356
         float tv = (u * A->tb[1] + v * A->tc[1]) + w * A->ta[1];
+        // all maps of this mesh in ONE 16-byte texel (DMesh.tex_comb): fetched once, unpacked where texture.rs:26-32 is applied
+        uint4 comb = make_uint4(0u, 0u, 0u, 0u);
+        const bool have_comb = M->tex_comb >= 0;
+        if (have_comb) {
+            const uint32_t t_offset = S.textures[M->tex_comb].offset;
+            const uint32_t W = (uint32_t)S.textures[M->tex_comb].width, H = (uint32_t)S.textures[M->tex_comb].height;
+            uint32_t x = (uint32_t)(clampf(tu, 0.0f, 0.999f) * (float)W);
+            if (x > W - 1u) x = W - 1u;
+            uint32_t y = (uint32_t)((1.0f - clampf(tv, 0.0f, 0.999f)) * (float)H);
+            if (y > H - 1u) y = H - 1u;
+            comb = ((const PT_CONST_AS uint4*)(S.texels + t_offset))[(size_t)y * W + x];
+        }
+        auto unpack3 = [](uint32_t px) { return mk3((float)(px & 0xffu) / 255.0f, (float)((px >> 8) & 0xffu) / 255.0f, (float)((px >> 16) & 0xffu) / 255.0f); };
         if (M->tex[4] >= 0) {                                            // geometry.rs:276-283
             f3 tan_approx = ld3(A->tan);
             f3 bitangent = normalize(cross(n, tan_approx));              // :360
             f3 tangent = normalize(cross(bitangent, n));                 // :361
-            f3 smp = tex_sample(S, M->tex[4], tu, tv);
+            f3 smp = have_comb ? unpack3(comb.z) : tex_sample(S, M->tex[4], tu, tv);
             f3 nv = smp * 2.0f - mk3(1.0f, 1.0f, 1.0f);                  // :282
             // Matrix3::from_cols(tangent, bitangent, normal) * nv            :283
             n = (tangent * nv.x + bitangent * nv.y) + n * nv.z;
@@ -489,10 +502,15 @@ __device__ __forceinline__ void resolve_hit(const DScene& S, const Best& b, f3 o
             load_material(S, M->material, s);                            // :255-256
         } else {                                                         // :259-269
             s.kind = MAT_PARAMETERIZED;
-            s.albedo   = (M->tex[0] >= 0) ? tex_sample(S, M->tex[0], tu, tv) : mk3(0.0f, 0.0f, 0.0f);
-            s.emission = (M->tex[1] >= 0) ? tex_sample(S, M->tex[1], tu, tv) : mk3(0.0f, 0.0f, 0.0f);
-            s.metallic  = (M->tex[2] >= 0) ? tex_sample(S, M->tex[2], tu, tv).x : 0.0f;
-            s.roughness = (M->tex[3] >= 0) ? tex_sample(S, M->tex[3], tu, tv).x : 1.0f;
+            if (have_comb) {        // absent maps were filled with their defaults' bytes (0, 0, 0, 255): same values
+                s.albedo = unpack3(comb.x); s.emission = unpack3(comb.y);
+                s.metallic = (float)(comb.x >> 24) / 255.0f; s.roughness = (float)(comb.y >> 24) / 255.0f;
+            } else {
+                s.albedo   = (M->tex[0] >= 0) ? tex_sample(S, M->tex[0], tu, tv) : mk3(0.0f, 0.0f, 0.0f);
+                s.emission = (M->tex[1] >= 0) ? tex_sample(S, M->tex[1], tu, tv) : mk3(0.0f, 0.0f, 0.0f);
+                s.metallic  = (M->tex[2] >= 0) ? tex_sample(S, M->tex[2], tu, tv).x : 0.0f;
+                s.roughness = (M->tex[3] >= 0) ? tex_sample(S, M->tex[3], tu, tv).x : 1.0f;
+            }
             const float PI = 3.14159265358979323846f;
             s.brdf_diffuse = mk3(s.albedo.x / PI, s.albedo.y / PI, s.albedo.z / PI);   // materials.rs:128
             s.ior = 0.0f;
