@@ -26,7 +26,8 @@
 // computed ones by at most  du|e1| + dv|e2| <= rho = 2 eps |d| E2 (16 Sr + 14 L) / 1e-4 + 11 eps L  in space and
 // dt = 2 (8.1 eps E2 Sr / 1e-4 + t_max (B + 2.001 eps))  along the ray  (Sr >= |o - vertex|, L = longest stored edge).
 // Hence: the test passes => the exact line meets the triangle's box grown by rho at a parameter in [t_min - dt, t_max + dt].
-// The device pads by 4 rho + 16 eps Sr (its own f32 slab arithmetic moves a box face by <= 3 eps Sr) and hands any ray with
+// The device pads by 4 rho + 16 eps Sr, applied to the differences (bmin - o) - pad and (bmax - o) + pad — never to o itself:
+// a mesh far from its object-space origin has |o| >> pad — (its own f32 slab arithmetic moves a box face by <= 3 eps Sr) and hands any ray with
 // B > 1/2 or non-finite inputs to the plain reference walk.  Meshes whose scale makes the 1e-4 test void (obj/drone.obj in
 // object space: |e1||e2||d| ~ 1e5) never qualify: there the reference can accept arbitrarily grazing triangles from
 // arbitrarily far away, and no finite padding is conservative.

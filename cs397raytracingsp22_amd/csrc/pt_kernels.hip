@@ -1787,23 +1787,25 @@ __device__ __forceinline__ bool two_stage_pad(const PT_CONST_AS DMeshF* F, f3 o,
     return (B <= 0.5f) && (Sr <= 1.0e12f) && (rho_out <= 1.0e30f) && (dt_out <= 1.0e30f);
 }
 
-// AABB test of pass 1: the box grown by rho (bmin against o + rho, bmax against o - rho), parameter range [t_lo, t_hi]
-__device__ __forceinline__ bool slab_padded(f3 bmin, f3 bmax, f3 op, f3 om, f3 inv_d, float t_lo, float t_hi) {
+// AABB test of pass 1: the box grown by rho, parameter range [t_lo, t_hi].  The padding is applied to the DIFFERENCES
+// (bmin - o) - rho and (bmax - o) + rho: a mesh far from its object-space origin has |o| >> rho, and o + rho would round
+// the padding away.
+__device__ __forceinline__ bool slab_padded(f3 bmin, f3 bmax, f3 o, float rho, f3 inv_d, float t_lo, float t_hi) {
     float tmin = t_lo, tmax = t_hi;
     {
-        float t0 = (bmin.x - op.x) * inv_d.x, t1 = (bmax.x - om.x) * inv_d.x;
+        float t0 = ((bmin.x - o.x) - rho) * inv_d.x, t1 = ((bmax.x - o.x) + rho) * inv_d.x;
         bool sw = inv_d.x < 0.0f;
         float ta = sw ? t1 : t0, tb = sw ? t0 : t1;
         tmin = fmaxf(ta, tmin); tmax = fminf(tb, tmax);
     }
     {
-        float t0 = (bmin.y - op.y) * inv_d.y, t1 = (bmax.y - om.y) * inv_d.y;
+        float t0 = ((bmin.y - o.y) - rho) * inv_d.y, t1 = ((bmax.y - o.y) + rho) * inv_d.y;
         bool sw = inv_d.y < 0.0f;
         float ta = sw ? t1 : t0, tb = sw ? t0 : t1;
         tmin = fmaxf(ta, tmin); tmax = fminf(tb, tmax);
     }
     {
-        float t0 = (bmin.z - op.z) * inv_d.z, t1 = (bmax.z - om.z) * inv_d.z;
+        float t0 = ((bmin.z - o.z) - rho) * inv_d.z, t1 = ((bmax.z - o.z) + rho) * inv_d.z;
         bool sw = inv_d.z < 0.0f;
         float ta = sw ? t1 : t0, tb = sw ? t0 : t1;
         tmin = fmaxf(ta, tmin); tmax = fminf(tb, tmax);
@@ -1815,7 +1817,7 @@ __device__ __forceinline__ bool slab_padded(f3 bmin, f3 bmax, f3 op, f3 om, f3 i
 // nothing below can be reached otherwise); sets up the object-space ray and the padded walk.  `fallback` receives the bits
 // of entered meshes the bound does not cover for this ray.
 __device__ __forceinline__ bool enter_next_mesh_f(const DScene& S, int& m, uint32_t mask, f3 o, f3 d, float t_min, float t_max,
-                                                  f3& oo, f3& od, f3& inv_d, f3& op, f3& om, float& t_lo, float& t_hi,
+                                                  f3& oo, f3& od, f3& inv_d, float& rho_out, float& t_lo, float& t_hi,
                                                   int& fi, int& fend, int& ftb, uint32_t& fallback) {
     cf4_ptr gn = (cf4_ptr)S.nodes;
     for (; m < S.n_meshes && m < kTwoStageMaxMeshes; m++) {
@@ -1830,7 +1832,7 @@ __device__ __forceinline__ bool enter_next_mesh_f(const DScene& S, int& m, uint3
         auto F = &S.meshf[m];
         float rho, dt;
         if (!two_stage_pad(F, oo, od, t_max, rho, dt)) { fallback |= 1u << m; continue; }
-        op = mk3(oo.x + rho, oo.y + rho, oo.z + rho); om = mk3(oo.x - rho, oo.y - rho, oo.z - rho);
+        rho_out = rho;
         t_lo = t_min - dt; t_hi = t_max + dt;
         fi = F->fnode_begin; fend = F->fnode_end; ftb = F->ftri_begin;
         return true;
@@ -1861,8 +1863,8 @@ __global__ __launch_bounds__(256, PT_TRAV_WAVES) void wf_trav_f(WfArgs A) {
 
     bool have = false, atleaf = false;
     uint32_t vi = 0, pos = 0, nc = 0, fb = 0;
-    f3 too = mk3(0.0f, 0.0f, 0.0f), tod = too, tinv = too, op = too, om = too;
-    float t_lo = 0.0f, t_hi = 0.0f;
+    f3 too = mk3(0.0f, 0.0f, 0.0f), tod = too, tinv = too;
+    float trho = 0.0f, t_lo = 0.0f, t_hi = 0.0f;
     int tm = 0, fi = 0, fend = 0, ftb = 0;
     float4 c0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), c1 = c0;
     const int last_fnode = S.n_fnodes - 1;          // clamp for the load that follows the last node of a tree
@@ -1892,7 +1894,7 @@ __global__ __launch_bounds__(256, PT_TRAV_WAVES) void wf_trav_f(WfArgs A) {
                 const float4 q0 = A.st_out[st_idx(0, pos, cap)], q1 = A.st_out[st_idx(1, pos, cap)];
                 const f3 o = mk3(q0.x, q0.y, q0.z), d = mk3(q0.w, q1.x, q1.y);
                 nc = 0; fb = 0; tm = 0; atleaf = false;
-                if (enter_next_mesh_f(S, tm, A.trav_mask, o, d, t_min, t_max, too, tod, tinv, op, om, t_lo, t_hi, fi, fend, ftb, fb)) {
+                if (enter_next_mesh_f(S, tm, A.trav_mask, o, d, t_min, t_max, too, tod, tinv, trho, t_lo, t_hi, fi, fend, ftb, fb)) {
                     c0 = FN[2 * fi]; c1 = FN[2 * fi + 1];
                     have = true;
                 } else {
@@ -1915,7 +1917,7 @@ __global__ __launch_bounds__(256, PT_TRAV_WAVES) void wf_trav_f(WfArgs A) {
 #pragma unroll
             for (int j = 0; j < PT_TRAVF_BURST; j++) {
                 const bool act = have & !atleaf & (fi < fend);
-                const bool hit = slab_padded(mk3(c0.x, c0.y, c0.z), mk3(c1.x, c1.y, c1.z), op, om, tinv, t_lo, t_hi);
+                const bool hit = slab_padded(mk3(c0.x, c0.y, c0.z), mk3(c1.x, c1.y, c1.z), too, trho, tinv, t_lo, t_hi);
                 const bool leaf = __float_as_int(c1.w) >= 0;
                 const bool stop = act & hit & leaf;                      // reached a leaf: its triangles are tested in a leaf step
                 const int nxt = hit ? fi + 1 : __float_as_int(c0.w);
@@ -1944,7 +1946,7 @@ __global__ __launch_bounds__(256, PT_TRAV_WAVES) void wf_trav_f(WfArgs A) {
             tm++;
             const float4 q0 = A.st_out[st_idx(0, pos, cap)], q1 = A.st_out[st_idx(1, pos, cap)];
             const f3 o = mk3(q0.x, q0.y, q0.z), d = mk3(q0.w, q1.x, q1.y);
-            if (enter_next_mesh_f(S, tm, A.trav_mask, o, d, t_min, t_max, too, tod, tinv, op, om, t_lo, t_hi, fi, fend, ftb, fb)) {
+            if (enter_next_mesh_f(S, tm, A.trav_mask, o, d, t_min, t_max, too, tod, tinv, trho, t_lo, t_hi, fi, fend, ftb, fb)) {
                 c0 = FN[2 * fi]; c1 = FN[2 * fi + 1];
             } else {
                 A.cand_hdr[vi] = make_uint2(pos, nc | (fb << 8));

@@ -7,8 +7,8 @@
 //         depth-first walk REPLAYED over the union of the root-to-candidate paths only, in index order, with the running bound.
 // Ray families include the adversarial ones for the padding bound: rays almost IN a triangle's plane (grazing), through
 // vertices and along edges, from far away, with tiny and huge |d|.
-// Prints one JSON line of work statistics.  usage: two_stage_check <mesh.bin> <scale> <n_rays> <seed>
-//   mesh.bin: int32 n_vertices, int32 n_triangles, float positions[3 nv], uint32 indices[3 nt]; positions are multiplied by <scale>
+// Prints one JSON line of work statistics.  usage: two_stage_check <mesh.bin> <scale> <n_rays> <seed> [offset]
+//   mesh.bin: int32 n_vertices, int32 n_triangles, float positions[3 nv], uint32 indices[3 nt]; positions become p * scale + offset
 #include <cstdio>
 #include <cstdlib>
 #include <climits>
@@ -61,7 +61,8 @@ int main(int argc, char** argv) {
     if (fread(pos.data(), 4, pos.size(), f) != pos.size() || fread(idx.data(), 4, idx.size(), f) != idx.size()) return 2;
     fclose(f);
     const float scale = (float)atof(argv[2]); const long n_rays = atol(argv[3]); const unsigned seed = (unsigned)atoi(argv[4]);
-    for (float& p : pos) p *= scale;
+    const float offset = argc > 5 ? (float)atof(argv[5]) : 0.0f;         // the mesh sits far from its object-space origin
+    for (float& p : pos) p = p * scale + offset;
 
     std::vector<float> nodes, fnodes, ftris, tris((size_t)nt * 12, 0.0f);
     RefTree rt{ pos.data(), idx.data(), &nodes };
@@ -143,17 +144,16 @@ int main(int argc, char** argv) {
             else {
                 struct Cand { float t; int tri; };
                 std::vector<Cand> cands;
-                // padded slab: bmin against o + rho, bmax against o - rho  ==  (bmin - rho, bmax + rho) against o
-                const R3 op{ o.x + pad.rho, o.y + pad.rho, o.z + pad.rho }, om{ o.x - pad.rho, o.y - pad.rho, o.z - pad.rho };
+                // padded slab: the padding is applied to the differences (bmin - o) - rho, (bmax - o) + rho (as the device does)
                 const float t_lo = t_min - pad.dt, t_hi = t_max + pad.dt;
                 int i = 0;
                 while (i < n_f) {
                     const float* n = &fnodes[(size_t)i * 8];
                     f_nodes++;
                     float tmin = t_lo, tmax = t_hi;
-                    const float opv[3] = { op.x, op.y, op.z }, omv[3] = { om.x, om.y, om.z }, ii[3] = { inv.x, inv.y, inv.z };
+                    const float ov[3] = { o.x, o.y, o.z }, ii[3] = { inv.x, inv.y, inv.z };
                     for (int a = 0; a < 3; a++) {
-                        const float t0 = (n[a] - opv[a]) * ii[a], t1 = (n[4 + a] - omv[a]) * ii[a];
+                        const float t0 = ((n[a] - ov[a]) - pad.rho) * ii[a], t1 = ((n[4 + a] - ov[a]) + pad.rho) * ii[a];
                         const bool sw = ii[a] < 0.0f;
                         const float ta = sw ? t1 : t0, tb = sw ? t0 : t1;
                         tmin = fmaxf(ta, tmin); tmax = fminf(tb, tmax);
