@@ -1841,6 +1841,9 @@ __device__ __forceinline__ bool enter_next_mesh_f(const DScene& S, int& m, uint3
 }
 
 // pass 1: persistent walkers over the traversal queue (work distribution and refill exactly as wf_trav)
+// (Negative result, round 2: flag bits in the queue word — "enters a reference-walk mesh" / "enters a two-stage mesh", so that each
+// walker skips the entries that are not for it without touching the path state — need wf_main to test EVERY mesh root instead
+// of stopping at the first one entered: wf_main +2.5 ms on cfg2, +1.2 ms on the HEAD scene, wf_trav_f only -0.3 ms.)
 __global__ __launch_bounds__(256, PT_TRAV_WAVES) void wf_trav_f(WfArgs A) {
     const DScene& S = A.S;
     const uint32_t n_q = A.hdr[2];
@@ -1868,9 +1871,15 @@ __global__ __launch_bounds__(256, PT_TRAV_WAVES) void wf_trav_f(WfArgs A) {
     int tm = 0, fi = 0, fend = 0, ftb = 0;
     float4 c0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), c1 = c0;
     const int last_fnode = S.n_fnodes - 1;          // clamp for the load that follows the last node of a tree
+#ifdef PT_TRAV_DIAG
+    unsigned long long dg_trips = 0, dg_bsteps = 0, dg_blanes = 0, dg_lsteps = 0, dg_llanes = 0, dg_refills = 0, dg_rlanes = 0, dg_walks = 0;
+#endif
 
     while (true) {
         // ---- refill idle lanes ----
+        // (Negative result, round 2: only 23 % of the HEAD scene's queue entries enter the sphere's root box, so one refill round
+        // leaves most idle lanes idle — 24.6 of 64 lanes live in an F-node step — but looping the refill up to 8 times until the
+        // wave is busy made wf_trav_f slower, 7.5 -> 7.85 ms: each round is a dependent queue -> state gather.)
         unsigned long long need = __builtin_amdgcn_ballot_w64(!have);
         const uint32_t n_idle = (uint32_t)__popcll(need);
         if ((n_idle >= A.refill_min || n_idle == 64u) && !drained) {
@@ -1903,11 +1912,17 @@ __global__ __launch_bounds__(256, PT_TRAV_WAVES) void wf_trav_f(WfArgs A) {
             }
             wnext += min(avail, n_idle);
             if (wnext < wend) { const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)wnext); while (A.trav_pfx[wlo + 1] <= w) wlo++; }
+#ifdef PT_TRAV_DIAG
+            dg_refills++; dg_rlanes += (unsigned long long)__popcll(__builtin_amdgcn_ballot_w64(take)); dg_walks += (unsigned long long)__popcll(__builtin_amdgcn_ballot_w64(take & have));
+#endif
         }
         if (__builtin_amdgcn_ballot_w64(have) == 0ull) {
             if (drained) break;
             continue;
         }
+#ifdef PT_TRAV_DIAG
+        dg_trips++;
+#endif
 
         // ---- one voted step: a burst of F-node box tests, or the triangle tests of the leaves reached ----
         const bool walking = have & !atleaf;
@@ -1917,6 +1932,9 @@ __global__ __launch_bounds__(256, PT_TRAV_WAVES) void wf_trav_f(WfArgs A) {
 #pragma unroll
             for (int j = 0; j < PT_TRAVF_BURST; j++) {
                 const bool act = have & !atleaf & (fi < fend);
+#ifdef PT_TRAV_DIAG
+                dg_bsteps++; dg_blanes += (unsigned long long)__popcll(__builtin_amdgcn_ballot_w64(act));
+#endif
                 const bool hit = slab_padded(mk3(c0.x, c0.y, c0.z), mk3(c1.x, c1.y, c1.z), too, trho, tinv, t_lo, t_hi);
                 const bool leaf = __float_as_int(c1.w) >= 0;
                 const bool stop = act & hit & leaf;                      // reached a leaf: its triangles are tested in a leaf step
@@ -1927,6 +1945,9 @@ __global__ __launch_bounds__(256, PT_TRAV_WAVES) void wf_trav_f(WfArgs A) {
                 if (move) { const int k = min(fi, last_fnode); c0 = FN[2 * k]; c1 = FN[2 * k + 1]; }
             }
         } else if (have & atleaf) {
+#ifdef PT_TRAV_DIAG
+            dg_lsteps++; dg_llanes += (unsigned long long)n_leaf;
+#endif
             const int payload = __float_as_int(c1.w);
             const int first = ftb + (payload >> 3), count = (payload & 7) + 1;
             for (int k = 0; k < count; k++) {
@@ -1954,6 +1975,12 @@ __global__ __launch_bounds__(256, PT_TRAV_WAVES) void wf_trav_f(WfArgs A) {
             }
         }
     }
+#ifdef PT_TRAV_DIAG
+    if (A.diag && lane == 0) {
+        atomicAdd(&A.diag[8], dg_trips); atomicAdd(&A.diag[9], dg_walks); atomicAdd(&A.diag[10], dg_bsteps); atomicAdd(&A.diag[11], dg_blanes);
+        atomicAdd(&A.diag[12], dg_lsteps); atomicAdd(&A.diag[13], dg_llanes); atomicAdd(&A.diag[14], dg_refills); atomicAdd(&A.diag[15], dg_rlanes);
+    }
+#endif
 }
 
 // pass 2: one thread per queued ray

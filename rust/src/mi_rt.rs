@@ -37,14 +37,27 @@ pub const MI_OPT_NO_TILE_MASKS: u32 = 1; pub const MI_OPT_REFERENCE_WALK: u32 = 
 
 #[link(name = "mi_rt")]
 extern "C" {
+    // every entry point of include/mi_rt.h (ABI 3), in header order
     pub fn mi_ctx_create(device: c_int, out: *mut *mut mi_ctx) -> c_int;
     pub fn mi_ctx_destroy(ctx: *mut mi_ctx);
     pub fn mi_scene_upload(ctx: *mut mi_ctx, scene: *const mi_scene_desc) -> c_int;
     pub fn mi_render(ctx: *mut mi_ctx, cam: *const mi_camera_desc, opts: *const mi_render_opts,
                      out_rgb_f32: *mut f32, out_rgb_u8: *mut u8, out_sig: *mut u32, stats: *mut mi_stats) -> c_int;
-    pub fn mi_reserve(ctx: *mut mi_ctx, cam: *const mi_camera_desc, world: i32, max_state_bytes: u64) -> c_int;
+    pub fn mi_compact_size(cam: *const mi_camera_desc, world: i32, tiles_total: *mut u32, tiles_padded: *mut u32) -> c_int;
+    // device-pointer building blocks (one process per GPU); pointers are device addresses, `stream` a hipStream_t
+    pub fn mi_render_tiles_device(ctx: *mut mi_ctx, cam: *const mi_camera_desc, opts: *const mi_render_opts,
+                                  d_compact_f32: *mut c_void, d_sig_u32: *mut c_void, stream: *mut c_void, stats: *mut mi_stats) -> c_int;
+    pub fn mi_render_samples_device(ctx: *mut mi_ctx, cam: *const mi_camera_desc, opts: *const mi_render_opts,
+                                    sample_begin: u32, sample_end: u32, d_accum_f32x4: *mut c_void,
+                                    d_compact_f32: *mut c_void, d_sig_u32: *mut c_void, stream: *mut c_void, stats: *mut mi_stats) -> c_int;
+    pub fn mi_unpermute_device(ctx: *mut mi_ctx, cam: *const mi_camera_desc, world: i32,
+                               d_gathered_f32: *const c_void, d_image_f32: *mut c_void, stream: *mut c_void) -> c_int;
+    pub fn mi_tonemap_device(ctx: *mut mi_ctx, cam: *const mi_camera_desc, d_image_f32: *const c_void, d_image_u8: *mut c_void, stream: *mut c_void) -> c_int;
     pub fn mi_last_kernel_ms(ctx: *mut mi_ctx, ms: *mut f32) -> c_int;
-    pub fn mi_abi_version() -> c_int;           // 3: assert at start-up that header and library agree
+    pub fn mi_reserve(ctx: *mut mi_ctx, cam: *const mi_camera_desc, world: i32, max_state_bytes: u64) -> c_int;
+    pub fn mi_last_pipeline_ms(ctx: *mut mi_ctx, out8: *mut f32) -> c_int;
+    pub fn mi_last_pipeline_counts(ctx: *mut mi_ctx, out8: *mut u64) -> c_int;
+    pub fn mi_last_diag(ctx: *mut mi_ctx, out16: *mut u64) -> c_int;
     // N GPUs of one node behind one blocking call (RCCL fan-in inside the library)
     pub fn mi_multi_create(n_devices: c_int, devices: *const c_int, out: *mut *mut mi_multi) -> c_int;
     pub fn mi_multi_destroy(m: *mut mi_multi);
@@ -54,6 +67,7 @@ extern "C" {
     pub fn mi_multi_render(m: *mut mi_multi, cam: *const mi_camera_desc, opts: *const mi_render_opts,
                            out_rgb_f32: *mut f32, out_rgb_u8: *mut u8, out_sig: *mut u32, stats: *mut mi_stats) -> c_int;
     pub fn mi_last_error() -> *const c_char;
+    pub fn mi_abi_version() -> c_int;           // 3: assert at start-up that header and library agree
 }
 
 /// Collected in `Scene.objects` order by the additive trait method

@@ -66,7 +66,8 @@ def main():
         if os.environ.get("MI_RT_WF_STAMPS"):
             out = (__import__("ctypes").c_uint64 * 16)()
             abi.check(ctx._lib.mi_last_diag(ctx._h, out))
-            print("RES diag", [int(v) for v in out][:8], flush=True)
+            print("RES diag wf_trav [trips, have, burst steps, burst lanes, leaf steps, leaf lanes, refills, rays]", [int(v) for v in out][:8],
+                  "wf_trav_f [trips, walks, burst steps, burst lanes, leaf steps, leaf lanes, refills, entries]", [int(v) for v in out][8:], flush=True)
         if a.check:
             _, _, s0, _ = ctx.render(cam, want_u8=False, want_sig=True, variant=a.variant, flags=a.flags)
             for name, fl in (("reference-walk", abi.MI_OPT_REFERENCE_WALK), ("no-tile-masks", abi.MI_OPT_NO_TILE_MASKS),
