@@ -801,9 +801,14 @@ __global__ __launch_bounds__(kBlock) void pt_megakernel(K1Args A) {
                 generate_ray(C, px, py, sample, P.rng, P.o, P.d);
                 P.T = mk3(1.0f, 1.0f, 1.0f); P.L = mk3(0.0f, 0.0f, 0.0f); P.depth = 0; P.sig = 0;
                 fresh = false;
+                if (C.path_depth == 0u) {                                 // :301 at level 0: the background, before any intersection
+                    if (SIG) sigsum += sig_end_depth(P.sig);
+                    sample++;
+                    fresh = true;
+                }
             }
         }
-        if (alive) {
+        if (alive && !fresh) {
         // ---- Scene::intersect_ray (tracing.rs:330-344): objects in order, wave-uniform index ----
         best.obj = -1; best.t = 0.0f; best.tri = -1; best.u = best.v = 0.0f;
         for (int k = 0; k < S.n_objects; k++) {
@@ -1205,11 +1210,16 @@ __global__ __launch_bounds__(kBlock, PT_MIN_WAVES) void pt_megakernel_voted(K1Ar
                         generate_ray(C, px, py, sample, P.rng, P.o, P.d);
                         P.T = mk3(1.0f, 1.0f, 1.0f); P.L = mk3(0.0f, 0.0f, 0.0f); P.depth = 0; P.sig = 0;
                         fresh = false;
+                        if (C.path_depth == 0u) {                         // :301 at level 0: the background, before any intersection
+                            if (SIG) sigsum += sig_end_depth(P.sig);
+                            sample++;
+                            fresh = true;
+                        }
                     }
                 }
                 // ---- (c) Scene::intersect_ray: the object list, then the mesh roots ----
                 if (DIAG) { unsigned long long t = __builtin_amdgcn_s_memtime(); dg_cycGen += t - dg_t1; dg_t1 = t; }
-                if (state == ST_A) {
+                if (state == ST_A && !fresh) {
                     best.obj = -1; best.t = 0.0f; best.tri = -1; best.u = best.v = 0.0f;
                     intersect_list(S, P.o, P.d, t_min, t_max, P.rng, best);
                     if (DIAG) did_list = true;
@@ -1404,6 +1414,11 @@ __global__ __launch_bounds__(kBlock, PT_MAIN_WAVES) void wf_main(WfArgs A) {
         if (alive) {
             rng_init(P.rng, A.seed_key, py * C.width + px, sample);
             generate_ray(C, px, py, sample, P.rng, P.o, P.d);
+            if (C.path_depth == 0u) {                                     // tracing.rs:301 at level 0: the background, before any intersection
+                if (SIG) P.sig = sig_end_depth(P.sig);
+                A.samp[(size_t)(sample - A.s_base) * A.npix + pix] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(P.sig));
+                alive = false;
+            }
         }
     } else {
         // which (class, shard) range of st_in does this block read?  (binary search in the block prefix:
@@ -1582,6 +1597,12 @@ __device__ __forceinline__ void bvh_bind(BvhNodesLds& B, const DScene& S, int) {
 
 // BS: threads per block.  256 for the small-LDS modes; 1024 (one block per CU) when the node array needs most of a
 // CU's 160 KB of LDS (meshes of ~1-2.5 k triangles: the drone's 3471 nodes = 111 KB).
+// (Negative result, round 2: TWO RAYS PER LANE in the 1024-thread form — it runs 4 waves per SIMD whatever its register count,
+// PMC shows 43 % of a wave's life parked at s_waitcnt, so two interleaved walks per lane looked free.  Built as a template
+// parameter with the per-ray state slimmed to fit 128 VGPRs without spills (o, d re-read for a further mesh, the hit record
+// merged in memory at the end of a walk, u and v recomputed by one more triangle test): bit-exact, but cfg4 wf_trav
+// 270 -> 321 ms, HEAD 54 -> 67 ms; the slimmed state alone, one ray per lane: 310 / 63 ms and cfg2 28.4 -> 34 ms.  The
+// walker is bound by VALU issue and LDS bank conflicts of its random 32-byte node reads, not by uncovered latency.)
 template <int LDS, int BS>
 __global__ __launch_bounds__(BS, (BS == 256 ? PT_TRAV_WAVES : 4)) void wf_trav(WfArgs A) {
     const DScene& S = A.S;

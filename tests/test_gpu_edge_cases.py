@@ -1,0 +1,106 @@
+"""Edge cases of the hot path, HIP (through the C ABI) against the oracle — same bars as tests/test_gpu_parity.py.
+The reference holds no tests; these are the boundaries its code has: an empty Scene.objects (every ray is background,
+tracing.rs:306), path_depth 0 (shade_ray returns the background before intersecting, tracing.rs:301), a 1x1 image, one
+sample per pixel and sample counts that are no perfect square (strata from floor(sqrt(n)), tracing.rs:165-170), images thinner
+than one 32-px tile, meshes whose root is a leaf (geometry.rs:95) or that consist of two triangles, a scene with nothing but
+a mesh, more than 64 list entries (tile masks switch themselves off), a tiny max_trace_dist, and a camera inside an object."""
+import numpy as np
+import pytest
+
+from cs397raytracingsp22_amd import (Camera, ConvexVolume, Dielectric, Isotropic, Lambertian, Metal, Plane, Scene, Sphere, StaticMesh,
+                                     Triangle, abi, cgmath, scenes)
+from cs397raytracingsp22_amd.objload import Mesh
+
+from test_gpu_parity import compare
+
+pytestmark = pytest.mark.gpu
+
+VARIANTS = [abi.MI_VARIANT_DEFAULT, abi.MI_VARIANT_VOTED, abi.MI_VARIANT_RECURSIVE]
+
+
+def camera(w, h, spp, depth, **kw):
+    args = dict(eyepoint=(0.0, 2.5, 7.5), view_dir=(0.0, 0.0, -1.0), up=(0.0, 1.0, 0.0), path_depth=depth, path_samples=1,
+                screen_width=w, screen_height=h, focal_length=0.8, focus_dist=5.0, lens_radius=0.0, aa_sample_count=spp,
+                max_trace_dist=100.0, gamma=2.0)
+    args.update(kw)
+    return Camera(**args)
+
+
+def tiny_mesh(n_tris):
+    """n_tris triangles in a fan around the y axis, one vertex set per triangle (tobj single_index layout)."""
+    pos, nrm, uv, idx = [], [], [], []
+    for k in range(n_tris):
+        a0, a1 = 2.0 * np.pi * k / max(n_tris, 3), 2.0 * np.pi * (k + 1) / max(n_tris, 3)
+        tri = [(0.0, 1.0, 0.0), (np.cos(a0), 0.0, np.sin(a0)), (np.cos(a1), 0.0, np.sin(a1))]
+        n = np.cross(np.subtract(tri[1], tri[0]), np.subtract(tri[2], tri[0]))
+        n = n / np.linalg.norm(n)
+        for j, p in enumerate(tri):
+            pos.append(p); nrm.append(tuple(n)); uv.append(((j == 1) * 1.0, (j == 2) * 1.0)); idx.append(3 * k + j)
+    return Mesh(np.asarray(pos, np.float32), np.asarray(nrm, np.float32), np.asarray(uv, np.float32), np.asarray(idx, np.uint32), f"fan{n_tris}")
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_empty_scene_is_background(gpu_ctx, orc, variant):
+    st = compare(gpu_ctx, orc, Scene(camera(70, 45, 4, 5), []), variant=variant)
+    assert st.samples == 70 * 45 * 4
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_path_depth_zero_never_intersects(gpu_ctx, orc, variant):
+    sc = scenes.config2(64, 48, 4, 0)
+    compare(gpu_ctx, orc, sc, variant=variant)
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+@pytest.mark.parametrize("w,h,spp,depth", [(1, 1, 1, 1), (1, 1, 7, 3), (33, 1, 2, 4), (1, 33, 3, 4), (31, 31, 5, 2), (65, 2, 10, 6)])
+def test_tiny_images_and_odd_sample_counts(gpu_ctx, orc, variant, w, h, spp, depth):
+    compare(gpu_ctx, orc, scenes.config2(w, h, spp, depth), variant=variant, seed=w * 131 + h)
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+@pytest.mark.parametrize("n_tris", [1, 2, 3])
+def test_mesh_of_one_two_three_triangles(gpu_ctx, orc, variant, n_tris):
+    """One triangle: the root IS a leaf and is never box-tested (geometry.rs:95); two: the smallest interior node."""
+    xf = cgmath.mul(cgmath.from_translation((0.0, 1.5, 0.0)), cgmath.from_angle_x(35.0), cgmath.from_scale(2.0))
+    mesh = StaticMesh(tiny_mesh(n_tris), Lambertian(albedo=(0.8, 0.3, 0.2), emission=(0.1, 0.1, 0.1)), [None] * 5, xf)
+    sc = Scene(camera(80, 60, 4, 4), scenes.cornell_walls() + [mesh])
+    compare(gpu_ctx, orc, sc, variant=variant)
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_scene_with_nothing_but_a_mesh(gpu_ctx, orc, variant):
+    xf = cgmath.mul(cgmath.from_translation((0.0, 1.5, 0.0)), cgmath.from_scale(1.5))
+    sc = Scene(camera(90, 64, 4, 6), [StaticMesh(scenes.load_asset_mesh("teapot"), Metal(albedo=(0.9, 0.8, 0.5), emission=(0.2, 0.2, 0.2), roughness=0.2),
+                                                  [None] * 5, xf)])
+    compare(gpu_ctx, orc, sc, variant=variant)
+
+
+@pytest.mark.parametrize("variant", [abi.MI_VARIANT_DEFAULT, abi.MI_VARIANT_VOTED])
+def test_more_than_64_list_entries(gpu_ctx, orc, variant):
+    """A 64-bit tile mask cannot describe 70 + 10 entries: masking must switch itself off, not truncate."""
+    rng = np.random.default_rng(5)
+    objs = scenes.cornell_walls()
+    for _ in range(70):
+        c = rng.uniform((-2.3, 0.3, -2.3), (2.3, 4.5, 2.3))
+        objs.append(Sphere(tuple(map(float, c)), float(rng.uniform(0.08, 0.25)), Lambertian(albedo=tuple(map(float, rng.uniform(0.2, 0.9, 3))), emission=(0, 0, 0))))
+    f = scenes.config1(100, 80, 4, 5)
+    sc = Scene(f.camera, objs)
+    flat = sc.flatten()
+    assert flat.desc.n_objects == len(objs) > 64
+    compare(gpu_ctx, orc, sc, variant=variant)
+    # and the masked / unmasked renders agree bit for bit
+    gpu_ctx.upload(flat)
+    _, _, s0, _ = gpu_ctx.render(sc.camera, seed=3, want_u8=False, want_sig=True)
+    _, _, s1, _ = gpu_ctx.render(sc.camera, seed=3, want_u8=False, want_sig=True, flags=abi.MI_OPT_NO_TILE_MASKS)
+    assert np.array_equal(s0, s1)
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_tiny_max_trace_dist_and_camera_inside_objects(gpu_ctx, orc, variant):
+    """max_trace_dist shorter than the room (most rays end as background although geometry lies ahead), the eye inside a
+    glass sphere and inside a ConvexVolume (t_entr < 0: geometry.rs:501-513)."""
+    objs = scenes.cornell_walls() + [Sphere((0.0, 2.5, 7.5), 0.6, Dielectric(1.5)),
+                                     ConvexVolume(Sphere((0.0, 2.5, 7.0), 2.0, Dielectric(1.5)), Isotropic(albedo=(0.9, 0.9, 0.9)), 0.8),
+                                     Plane((0.0, -0.2, 0.0), (0.0, 1.0, 0.0), Lambertian(albedo=(0.4, 0.4, 0.4), emission=(0, 0, 0)))]
+    for dist in (100.0, 6.0, 0.5):
+        compare(gpu_ctx, orc, Scene(camera(72, 54, 4, 6, max_trace_dist=dist), objs), variant=variant)
