@@ -870,7 +870,7 @@ static bool tile_masks(mi_ctx* c, const mi_camera_desc* cam, uint32_t flags) {
         }
         c->h_tile_mask[(size_t)j * tx + i] = mask;
         unsigned long long mm = 0xffffffffull;
-        for (int m = 0; m < n_mesh; m++) {
+        for (int m = 0; m < n_mesh && m < 32; m++) {          // the mesh word has 32 bits: meshes 32, 33, ... are never culled
             const mi_ctx::MeshBox& B = c->h_mesh_box[(size_t)m];
             if (!B.cullable) continue;
             bool cull = false;
@@ -887,7 +887,7 @@ static bool tile_masks(mi_ctx* c, const mi_camera_desc* cam, uint32_t flags) {
         }
         const unsigned long long ts_bits = (n_ts >= 64) ? ~0ull : ((1ull << n_ts) - 1ull);
         const unsigned long long mesh_bits = (n_mesh >= 32) ? 0xffffffffull : ((1ull << n_mesh) - 1ull);
-        if ((mask & ts_bits) == 0ull && (mm & mesh_bits) == 0ull && c->h_n_unmasked == 0) mm |= 1ull << 63;
+        if ((mask & ts_bits) == 0ull && (mm & mesh_bits) == 0ull && c->h_n_unmasked == 0 && n_mesh <= 32) mm |= 1ull << 63;
         c->h_tile_mask[n_tiles + (size_t)j * tx + i] = mm;
     }
     c->mask_cam = *cam; c->mask_valid = false;              // valid once uploaded
@@ -895,7 +895,7 @@ static bool tile_masks(mi_ctx* c, const mi_camera_desc* cam, uint32_t flags) {
         size_t bits = 0, mbits = 0, dead = 0;
         for (size_t t = 0; t < n_tiles; t++) {
             bits += (size_t)__builtin_popcountll(c->h_tile_mask[t] & ((n_ts >= 64) ? ~0ull : ((1ull << n_ts) - 1ull)));
-            mbits += (size_t)__builtin_popcountll(c->h_tile_mask[n_tiles + t] & ((1ull << n_mesh) - 1ull));
+            mbits += (size_t)__builtin_popcountll(c->h_tile_mask[n_tiles + t] & ((n_mesh >= 32) ? 0xffffffffull : ((1ull << n_mesh) - 1ull)));
             dead += (size_t)(c->h_tile_mask[n_tiles + t] >> 63);
         }
         fprintf(stderr, "[mi_rt] tile masks: %zu tiles, %.2f of %d list entries and %.2f of %d meshes kept per tile, %zu dead tiles\n",
@@ -951,7 +951,7 @@ static int render_tiles_wavefront(mi_ctx* c, const K1Args& k, const mi_camera_de
     // triangles (what the megakernels stage), 0 = everything from global memory.  The LDS window is the head of the node
     // pool up to the last tree wf_trav walks (the scene compiler places those trees first).
     int ref_nodes = 0, ref_e2 = 0;
-    for (size_t m = 0; m < c->mesh_node_end.size() && m < 32; m++) if ((ref_mask >> m) & 1u) {
+    for (size_t m = 0; m < c->mesh_node_end.size(); m++) if (m >= 32 || ((ref_mask >> m) & 1u)) {     // meshes 32, 33, ... have no mask bit: always walked here
         ref_nodes = std::max(ref_nodes, c->mesh_node_end[m]); ref_e2 = std::max(ref_e2, c->mesh_e2_end[m]);
     }
     // LDS image of a walker block: the nodes (leaves carry a and e1 of their triangle) + the triangles' e2 vectors
@@ -1012,14 +1012,14 @@ static int render_tiles_wavefront(mi_ctx* c, const K1Args& k, const mi_camera_de
             HIP_TRY(launch_wf_prefix(cnt, cnt + 2 * S_, d_in_count, d_in_pfx, d_trav_pfx, d_hdr, c->h_hdr_dev, seq, stream));
             // persistent walkers; they leave at once when the queue is empty.  Successive launches merge their meshes' hits
             // into the hit record (strictly closer wins, ties go to the lower Scene.objects index: order-independent)
-            if (ref_mask) {
+            if (ref_mask || c->S.n_meshes > 32) {      // meshes 32, 33, ... have no mask bit: they always take the reference walk
                 a.trav_mask = ref_mask;
                 WF_TIMED(1, launch_wf_trav(a, trav_blocks, trav_lds_mode, trav_lds_bytes, &c->big_lds_enabled, stream));
             }
             if (ts_mask) {
                 a.trav_mask = ts_mask;
                 // the walkers of the first launch have advanced the shared queue cursor: rewind it (stream order)
-                if (ref_mask) HIP_TRY(hipMemsetAsync(a.trav_head, 0, sizeof(uint32_t), stream));
+                if (ref_mask || c->S.n_meshes > 32) HIP_TRY(hipMemsetAsync(a.trav_head, 0, sizeof(uint32_t), stream));
                 WF_TIMED(3, launch_wf_trav_f(a, travf_blocks, stream));
                 WF_TIMED(4, launch_wf_replay(a, replay_blocks, stream));
             }

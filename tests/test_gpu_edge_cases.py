@@ -104,3 +104,27 @@ def test_tiny_max_trace_dist_and_camera_inside_objects(gpu_ctx, orc, variant):
                                      Plane((0.0, -0.2, 0.0), (0.0, 1.0, 0.0), Lambertian(albedo=(0.4, 0.4, 0.4), emission=(0, 0, 0)))]
     for dist in (100.0, 6.0, 0.5):
         compare(gpu_ctx, orc, Scene(camera(72, 54, 4, 6, max_trace_dist=dist), objs), variant=variant)
+
+
+@pytest.mark.parametrize("variant", [abi.MI_VARIANT_DEFAULT, abi.MI_VARIANT_VOTED])
+@pytest.mark.parametrize("flags", [0, abi.MI_OPT_TWO_STAGE])
+def test_more_than_32_meshes(gpu_ctx, orc, variant, flags):
+    """The per-tile mesh masks and the walkers' mesh masks are 32 bits wide: meshes 32, 33, ... must still be walked (and
+    their trees must be inside the walker's LDS window), whatever the masks say about the first 32."""
+    rng = np.random.default_rng(11)
+    objs = scenes.cornell_walls()
+    cube, teapot = scenes.load_asset_mesh("cube"), scenes.load_asset_mesh("teapot")
+    for k in range(37):
+        c = rng.uniform((-2.4, 0.4, -2.4), (2.4, 5.0, 2.0))
+        xf = cgmath.mul(cgmath.from_translation(tuple(map(float, c))), cgmath.from_angle_y(float(rng.uniform(0, 360))),
+                        cgmath.from_angle_x(float(rng.uniform(0, 90))), cgmath.from_scale(float(rng.uniform(0.15, 0.4))))
+        objs.append(StaticMesh(teapot if k in (5, 34) else cube, Lambertian(albedo=tuple(map(float, rng.uniform(0.2, 0.9, 3))), emission=(0, 0, 0)), [None] * 5, xf))
+    sc = Scene(scenes.config1(120, 90, 4, 6).camera, objs)
+    flat = sc.flatten()
+    assert flat.desc.n_meshes == 37
+    gpu_ctx.upload(flat)
+    f32, u8, sig, _ = gpu_ctx.render(sc.camera, seed=2, want_sig=True, variant=variant, flags=flags)
+    r32, r8, rsig, _ = orc.OracleScene(flat).render(sc.camera, seed=2)
+    assert int((sig != rsig).sum()) == 0
+    assert float(np.abs(f32 - r32).max()) <= 2e-5 * max(1.0, float(np.abs(r32).max()))
+    assert int(np.abs(u8.astype(int) - r8.astype(int)).max()) <= 1
