@@ -623,6 +623,23 @@ static int check_camera(const mi_camera_desc* cam) {
     if (cam->aa_sample_count == 0) return fail(MI_ERR_INVALID, "aa_sample_count must be >= 1");
     if ((uint32_t)sqrtf((float)cam->aa_sample_count) == 0) return fail(MI_ERR_INVALID, "aa_sample_count too small");
     if (!(cam->gamma > 0.0f) || !std::isfinite(cam->gamma)) return fail(MI_ERR_INVALID, "gamma must be finite and > 0 (tracing.rs:254 raises to 1/gamma)");
+    // A camera that makes every ray non-finite is refused, not rendered.  The reference would render it: its tests then "hit"
+    // with a NaN distance wherever every reject comparison is false (geometry.rs:338-349, 401-410) and Scene keeps the FIRST
+    // such hit in Scene.objects order (tracing.rs:335, NaN < x is false) — a result that depends on the evaluation order
+    // of unordered comparisons, which the kind-grouped object list of the kernels does not keep.
+    for (int k = 0; k < 3; k++)
+        if (!std::isfinite(cam->eyepoint[k]) || !std::isfinite(cam->view_dir[k]) || !std::isfinite(cam->up[k]))
+            return fail(MI_ERR_INVALID, "camera eyepoint / view_dir / up must be finite");
+    if (!std::isfinite(cam->focal_length) || !std::isfinite(cam->focus_dist) || !std::isfinite(cam->lens_radius) || std::isnan(cam->max_trace_dist))
+        return fail(MI_ERR_INVALID, "camera focal_length / focus_dist / lens_radius must be finite, max_trace_dist not NaN");
+    {
+        // tracing.rs:188: rotation.x = view_dir.cross(up).normalize(), in f32 as the kernels evaluate it
+        const float* v = cam->view_dir; const float* u = cam->up;
+        const float cx = v[1] * u[2] - v[2] * u[1], cy = v[2] * u[0] - v[0] * u[2], cz = v[0] * u[1] - v[1] * u[0];
+        const float m2 = (cx * cx + cy * cy) + cz * cz;
+        if (!(m2 > 0.0f) || !std::isfinite(1.0f / sqrtf(m2)))
+            return fail(MI_ERR_INVALID, "view_dir x up is zero or not finite: the camera basis is singular and every ray would be NaN (tracing.rs:188)");
+    }
     return MI_OK;
 }
 

@@ -102,7 +102,7 @@ def test_tiny_max_trace_dist_and_camera_inside_objects(gpu_ctx, orc, variant):
     objs = scenes.cornell_walls() + [Sphere((0.0, 2.5, 7.5), 0.6, Dielectric(1.5)),
                                      ConvexVolume(Sphere((0.0, 2.5, 7.0), 2.0, Dielectric(1.5)), Isotropic(albedo=(0.9, 0.9, 0.9)), 0.8),
                                      Plane((0.0, -0.2, 0.0), (0.0, 1.0, 0.0), Lambertian(albedo=(0.4, 0.4, 0.4), emission=(0, 0, 0)))]
-    for dist in (100.0, 6.0, 0.5):
+    for dist in (100.0, 6.0, 0.5, float("inf")):           # inf: "no limit" is a legitimate max_trace_dist
         compare(gpu_ctx, orc, Scene(camera(72, 54, 4, 6, max_trace_dist=dist), objs), variant=variant)
 
 
@@ -128,3 +128,46 @@ def test_more_than_32_meshes(gpu_ctx, orc, variant, flags):
     assert int((sig != rsig).sum()) == 0
     assert float(np.abs(f32 - r32).max()) <= 2e-5 * max(1.0, float(np.abs(r32).max()))
     assert int(np.abs(u8.astype(int) - r8.astype(int)).max()) <= 1
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+@pytest.mark.parametrize("case", ["degenerate_objects", "zero_mesh_normals"])
+def test_degenerate_geometry(gpu_ctx, orc, variant, case):
+    """Garbage in, the reference's garbage out: zero-area triangles, a zero-radius sphere and zero vertex normals
+    (normalize(0) = NaN normal, geometry.rs:356 -> NaN scatter directions) walk through the same decisions as the oracle."""
+    objs = scenes.config2(8, 8, 1, 1).objects
+    if case == "degenerate_objects":
+        objs = objs + [Triangle((0, 1, 0), (0, 1, 0), (0, 1, 0), Lambertian(albedo=(0.5, 0.5, 0.5), emission=(1, 1, 1))),
+                       Triangle((-1, 1, 0), (0, 1, 0), (1, 1, 0), Lambertian(albedo=(0.5, 0.5, 0.5), emission=(1, 1, 1))),
+                       Sphere((0.5, 2.0, 1.0), 0.0, Metal(albedo=(0.9, 0.9, 0.9), emission=(0, 0, 0), roughness=0.0))]
+    else:
+        m = tiny_mesh(3)
+        m.normals[:] = 0.0
+        xf = cgmath.mul(cgmath.from_translation((0.0, 1.0, 1.0)), cgmath.from_scale(2.0))
+        objs = objs[:12] + [StaticMesh(m, Lambertian(albedo=(0.7, 0.7, 0.7), emission=(0.2, 0.2, 0.2)), [None] * 5, xf)]
+    sc = Scene(camera(48, 40, 4, 5), objs)
+    flat = sc.flatten()
+    gpu_ctx.upload(flat)
+    f32, u8, sig, _ = gpu_ctx.render(sc.camera, seed=4, want_sig=True, variant=variant)
+    r32, r8, rsig, _ = orc.OracleScene(flat).render(sc.camera, seed=4)
+    assert int((sig != rsig).sum()) == 0
+    fin = np.isfinite(r32)
+    assert np.array_equal(np.isfinite(f32), fin)
+    assert float(np.abs(f32[fin] - r32[fin]).max(initial=0.0)) <= 2e-5 * max(1.0, float(np.abs(r32[fin]).max(initial=0.0)))
+    assert int(np.abs(u8.astype(int) - r8.astype(int)).max()) <= 1
+
+
+@pytest.mark.parametrize("field,value", [("up", (0.0, 0.0, -2.0)), ("view_dir", (0.0, 0.0, 0.0)), ("eyepoint", (0.0, float("nan"), 0.0)),
+                                         ("up", (0.0, float("inf"), 0.0)), ("focus_dist", float("nan")), ("max_trace_dist", float("nan"))])
+def test_cameras_that_make_every_ray_non_finite_are_refused(gpu_ctx, field, value):
+    """A DEVIATION from the reference, on purpose: the reference renders such a camera — every ray is NaN,
+    its tests 'hit' with NaN distances and Scene keeps the first such hit in Scene.objects order (tracing.rs:335), which the
+    kind-grouped object list of the kernels does not reproduce.  The library says so instead of returning a different image."""
+    sc = scenes.config2(32, 32, 1, 2)
+    gpu_ctx.upload(sc.flatten())
+    cam = camera(32, 32, 1, 2, **{field: value})
+    with pytest.raises(abi.MiError) as ei:
+        gpu_ctx.render(cam)
+    assert ei.value.code == abi.MI_ERR_INVALID
+    f32, _, _, _ = gpu_ctx.render(camera(32, 32, 1, 2))          # the context is still usable
+    assert np.isfinite(f32).all()
