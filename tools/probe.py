@@ -91,6 +91,9 @@ def main():
             torch.cuda.synchronize()
             walls.append((time.perf_counter() - t0) * 1e3 / a.reps)
             kerns.append(k / a.reps)
+            if os.environ.get("MI_RT_WF_KERNEL_TIMING") == "1" and r in (0, a.world - 1):      # per-kernel sums of the last frame of this rank
+                print(f"RES {tag} world={a.world} rank {r}: wall {walls[-1]:.2f} ms", {k2: round(v, 2) for k2, v in ctx.last_pipeline_ms().items()},
+                      ctx.last_pipeline_counts(), flush=True)
         print(f"RES {tag} world={a.world}: wall max {max(walls):.2f} mean {np.mean(walls):.2f} ms | kernel max {max(kerns):.2f} ms", flush=True)
     ctx.close()
 
