@@ -145,6 +145,7 @@ struct mi_ctx {
         bool global_bvh = false;                        // never stage a BVH in LDS
         bool wf_stamps = false;                         // -DPT_WF_STAMPS builds: collect wf_main phase stamps
         bool debug_mask = false;                        // print tile-mask statistics
+        bool dump_launches = false;                     // print every pipeline launch's duration (needs per-launch events)
         uint32_t spin_timeout_ms = 120000;              // header wait: give up after this long without progress
     } tune;
 };
@@ -187,6 +188,7 @@ static int ctx_init(mi_ctx* c, const hipDeviceProp_t& prop) {
     t.global_bvh = getenv("MI_RT_GLOBAL_BVH") != nullptr;
     t.wf_stamps = getenv("MI_RT_WF_STAMPS") != nullptr;
     t.debug_mask = getenv("MI_RT_DEBUG_MASK") != nullptr;
+    t.dump_launches = getenv("MI_RT_WF_DUMP_LAUNCHES") != nullptr;
     env_u("MI_RT_SPIN_TIMEOUT_MS", t.spin_timeout_ms);
     if (t.vote_t < 1) t.vote_t = 1;
     if (t.k_steps < 1) t.k_steps = 1;
@@ -1075,6 +1077,10 @@ static int render_tiles_wavefront(mi_ctx* c, const K1Args& k, const mi_camera_de
     for (size_t e = 0; e + 1 < ev_used; e += 2) {
         float ms = 0.0f;
         if (hipEventElapsedTime(&ms, c->wf_ev[e], c->wf_ev[e + 1]) == hipSuccess) c->wf_ms[ev_kind[e] < 3 ? ev_kind[e] : ev_kind[e] + 1] += ms;
+        if (c->tune.dump_launches) {
+            static const char* const names[5] = { "wf_main", "wf_trav", "wf_reduce", "wf_trav_f", "wf_replay" };
+            fprintf(stderr, "[mi_rt] launch %zu %s %.4f ms\n", e / 2, names[ev_kind[e]], ms);
+        }
     }
     return MI_OK;
 }
