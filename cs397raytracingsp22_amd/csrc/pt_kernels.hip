@@ -57,7 +57,9 @@
                             // tree ends in pairs of sibling leaves): 29.4 -> 28.5 ms on cfg2, 71.7 -> 69.9 on cfg4 (0 = never)
 #endif
 #ifndef PT_TRAV_WAVES
-#define PT_TRAV_WAVES 6     // wf_trav: waves per SIMD (LDS admits 6 blocks of 26.8 KB per CU)
+#define PT_TRAV_WAVES 8     // wf_trav / wf_trav_f, 256-thread blocks: waves per SIMD the register allocator must allow.  8 = 64 VGPRs and 78 SGPRs
+                            // (9 scalar spills) so that eight blocks per CU really fit — 6 let the compiler take 67 VGPRs / 92 SGPRs, i.e. seven.
+                            // A/B at the end of round 2, cfg2 wf_trav: 6 / 7 / 8 -> 29.2 / 29.1 / 28.1 ms (HEAD scene: unchanged)
 #endif
 #ifndef PT_MIN_WAVES
 #define PT_MIN_WAVES 4      // waves per SIMD the register allocator must leave room for (<= 128 VGPRs)
