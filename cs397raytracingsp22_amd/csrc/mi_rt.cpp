@@ -138,7 +138,7 @@ struct mi_ctx {
         uint32_t vote_t = 2, vote_a = 1, k_steps = 8;   // voted megakernel
         uint32_t lds_pad = 0;                           // occupancy experiments
         uint32_t refill_min = 16;                       // wf_trav: refill idle lanes when at least this many are idle (A/B round 2: 32 / 16 / 8 -> 36.9 / 35.8 / 38.6 ms on cfg2)
-        uint32_t fuse_max = 1, fuse_min = 32;           // wf_main: in-launch continuation (rounds, lanes needed)
+        uint32_t fuse_max = 0, fuse_min = 32;           // wf_main: in-launch continuation (rounds: 0 = automatic; lanes needed)
         int trav_lds = -1;                              // wf_trav LDS mode override (-1 = automatic)
         int trav_bpc = 0;                               // wf_trav blocks per CU override (0 = automatic)
         int kernel_timing = -1;                         // per-launch HIP events: -1 = single-rank renders only
@@ -960,7 +960,11 @@ static int render_tiles_wavefront(mi_ctx* c, const K1Args& k, const mi_camera_de
     a.diag = nullptr;           // developer builds (-DPT_WF_STAMPS): phase stamps of wf_main
     if (c->tune.wf_stamps) { a.diag = c->d_diag; HIP_TRY(hipMemsetAsync(c->d_diag, 0, 16 * sizeof(unsigned long long), stream)); }
     a.refill_min = c->tune.refill_min;
-    a.fuse_max = c->tune.fuse_max; a.fuse_min = c->tune.fuse_min < 1 ? 1 : c->tune.fuse_min;
+    // further shade + intersect rounds inside one wf_main launch: one when meshes park part of every wave's rays for the walker
+    // (cfg2: 1 / 2 / 3 rounds -> 99 / 101 / 103 ms), two in a scene without meshes, where every live lane can go on
+    // (cfg5 at 512 spp: 1 / 2 / 3 / 5 rounds -> 281.6 / 271.8 / 278.4 / 287.7 ms; the cfg1 scene at 1080p: 46.6 / 42.9 / 47.4 / 48.1 ms)
+    a.fuse_max = c->tune.fuse_max ? c->tune.fuse_max : (c->S.n_meshes == 0 ? 2u : 1u);
+    a.fuse_min = c->tune.fuse_min < 1 ? 1 : c->tune.fuse_min;
     // Which meshes are walked how: the two-stage meshes (wf_trav_f + wf_replay), the rest through the reference's tree (wf_trav).
     const uint32_t all_meshes = c->S.n_meshes >= 32 ? 0xffffffffu : ((1u << c->S.n_meshes) - 1u);
     const uint32_t ts_mask = two_stage_mask(c, flags) & all_meshes;
