@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""A long run of the random-scene parity tests (tests/test_gpu_fuzz.py) over seeds the test suite does not use:
+
+    python tools/fuzz_campaign.py [first_seed] [count]
+
+Runs test_random_scene_parity and test_random_scene_random_modes for every seed in [first_seed, first_seed + count)
+against the oracle on the GPU box, prints one line per failure and a summary.  A one-off confidence run, not part of the suite.
+"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch  # noqa: E402,F401
+from cs397raytracingsp22_amd import Context  # noqa: E402
+from oracle import orc_py  # noqa: E402
+import test_gpu_fuzz as F  # noqa: E402
+
+
+def main():
+    first = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+    count = int(sys.argv[2]) if len(sys.argv) > 2 else 300
+    orc_py.build()
+    orc_py.load()
+    ctx = Context(0)
+    bad = 0
+    t0 = time.time()
+    for seed in range(first, first + count):
+        for fn in (F.test_random_scene_parity, F.test_random_scene_random_modes):
+            try:
+                fn(ctx, orc_py, seed)
+            except AssertionError as e:
+                bad += 1
+                print(f"FAIL {fn.__name__} seed {seed}: {str(e)[:200]}", flush=True)
+        if (seed - first) % 50 == 49:
+            print(f"... {seed - first + 1} seeds, {bad} failures, {time.time() - t0:.0f} s", flush=True)
+    print(f"fuzz campaign: seeds [{first}, {first + count}), 2 tests each: {bad} failures in {time.time() - t0:.0f} s", flush=True)
+    ctx.close()
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
