@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """bench.py — the driver's benchmark contract for the path-tracing hot path.
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W          any N >= 1, no launcher: N > 1 runs IN THIS PROCESS through the
+                                                         library's own multi-GPU entry point (mi_multi_*: native RCCL fan-in)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-         --master-port P bench.py --gpus N --steps K --warmup W
+         --master-port P bench.py --gpus N --steps K --warmup W        one process per GPU (dist.py, torch.distributed = RCCL)
 
 A "step" is one pass of the hot path over one frame: K1w (the wavefront path-tracing
 pipeline over this rank's tiles: wf_main / wf_trav once per path segment + wf_reduce) -> the
@@ -139,19 +140,138 @@ def cpu_baseline(sc, flat):
     rows = min(rows, H // stride)
     dt = run(min(1, stride - 1), rows, stride)
     n = W * rows * cam.aa_sample_count
-    model = "unknown CPU"
-    try:
-        with open("/proc/cpuinfo") as fh:
-            for line in fh:
-                if line.startswith("model name"):
-                    model = line.split(":", 1)[1].strip()
-                    break
-    except OSError:
-        pass
+    model = cpu_model()
     return {"value": n / dt / 1e6, "unit": "Msamples/s", "cores": threads, "kind": "port", "cpu": model, "build": build,
             "sample": f"{rows} full-width rows (every {stride}th row) of the same {W}x{H} frame, all {cam.aa_sample_count} spp: "
                       f"{n} samples in {dt:.1f} s after a {cal_rows}-row calibration pass (plain-C oracle, one task per scanline "
                       f"like rayon, tracing.rs:228; cores = worker threads = affinity mask capped by the cgroup CPU quota)"}
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown CPU"
+
+
+def report(args, sc, flat, world, backend, route, dt, kernel_ms, pipe, counts, extra_config=None):
+    """Rank 0's ONE JSON line.  `kernel_ms` = pipeline pass of the slowest device (HIP events on its launch stream), `pipe` the
+    per-kernel sums and `counts` the path counts of ONE device (device 0) over the timed steps."""
+    cam = sc.camera
+    samples_per_frame = cam.screen_width * cam.screen_height * cam.aa_sample_count
+    ms_per_step = dt / args.steps * 1e3
+    value = samples_per_frame * args.steps / dt / 1e6
+    b_sample, segs = algorithmic_bytes_per_sample(args.config, cam.aa_sample_count)
+    wavefront = args.variant in (0, 7)
+    per_step = {k: (v / args.steps) for k, v in pipe.items()}
+    # ---- HBM roofline of the dominant kernel group (the pipeline pass of ONE device) ----
+    pmc, why_not = (committed_pmc(args.config) if world == 1 and not args.spp and wavefront and not args.flags
+                    else (None, "not the profiled configuration"))
+    model_bytes = traffic_model(counts, flat.desc.n_meshes) if (wavefront and counts and counts["passes"]) else None
+    if pmc is not None and pmc.get("hbm_bytes_per_launch"):
+        traffic, traffic_source = float(pmc["hbm_bytes_per_launch"]), \
+            f"committed rocprofv3 PMC, profiles/traffic_{args.config}.json tag {pmc['tag']} (same kernel sources {pmc['source_hash']}); not measured in this run"
+    elif model_bytes is not None:
+        traffic, traffic_source = model_bytes, f"traffic model on this run's own path counts of device 0 ({why_not})"
+    else:
+        traffic, traffic_source = None, why_not
+    achieved = traffic / (kernel_ms * 1e-3) / 1e9 if (traffic and kernel_ms) else None
+    frac = achieved / HBM_PEAK_GBS if achieved is not None else None
+    if frac is not None:
+        assert frac <= 1.0, f"HBM roofline fraction {frac} > 1: traffic accounting is wrong"
+    valu = dom = None
+    valu_issue = valu_lane = None
+    if pmc is not None:
+        valu = {k: {"ms": v["ms"], "valu_insts": v["valu_insts"], "issue_frac": v["valu_issue_frac"], "active_lanes": v["active_lanes"],
+                    "lane_frac": (v["valu_issue_frac"] * v["active_lanes"] / 64.0 if v.get("valu_issue_frac") and v.get("active_lanes") else None),
+                    "hbm_GBps": v["hbm_GBps"], "hbm_frac": (v["hbm_GBps"] / HBM_PEAK_GBS if v.get("hbm_GBps") else None)}
+                for k, v in pmc.get("per_kernel", {}).items() if v.get("valu_insts") or v.get("hbm_bytes")}
+        if valu:
+            dom = max(valu, key=lambda k: valu[k]["ms"])
+            valu_issue, valu_lane = valu[dom]["issue_frac"], valu[dom]["lane_frac"]
+    out = {
+        "metric": "Msamples/sec (=rays/sec) at 1080p Cornell+teapot, 256 spp; 1/2/4/8 GPU",
+        "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic", "backend": backend,
+        "config": {"workload": f"{args.config}: {CONFIGS[args.config]}",
+                   "width": cam.screen_width, "height": cam.screen_height, "spp": cam.aa_sample_count,
+                   "path_depth": cam.path_depth, "parallelism": f"tiles32x32_mod{world}",
+                   "caller": "python ctypes over the C ABI (include/mi_rt.h)", "route": route,
+                   "segments_per_sample": segs, "msegments_per_s": (value * segs if segs else None),
+                   "multi_gpu_note": "N>1 numbers exist only where this script ran on a multi-GPU node; "
+                                     "the builder's own N>1 figures are single-GPU rehearsals (DESIGN.md section 6)"},
+        # Two resources bound this path and NEITHER is saturated (DESIGN.md section 5): `frac` is the HBM fraction of the
+        # pipeline pass (the key the bench contract names), `valu_lane_frac` the VALU lane-throughput fraction of the
+        # dominant kernel.  "bound" names the roofline `achieved`/`peak`/`frac` are quoted on, not a claim that it binds.
+        "roofline": {"bound": "hbm",
+                     "kernel": "K1w pipeline pass (wf_main + wf_prefix + wf_trav per segment, wf_reduce)" if wavefront else "single-launch kernel",
+                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": frac,
+                     "valu_issue_frac": valu_issue, "valu_lane_frac": valu_lane, "valu_kernel": dom,
+                     "binding": "neither HBM nor VALU issue is saturated: latency of the dependent state gathers / LDS node fetches with "
+                                "partly filled waves (DESIGN.md section 5)",
+                     "traffic": traffic, "traffic_source": traffic_source,
+                     "traffic_model_bytes": model_bytes, "path_counts": counts,
+                     "kernel_ms": kernel_ms,
+                     "per_step_ms": ({"wf_main": per_step["wf_main_ms"], "wf_trav": per_step["wf_trav_ms"],
+                                      "wf_reduce": per_step["wf_reduce_ms"], "launches": per_step["launches"],
+                                      "wf_trav_f": per_step["wf_trav_f_ms"], "wf_replay": per_step["wf_replay_ms"]}
+                                     if per_step.get("launches") else None),
+                     "valu": valu,
+                     "algorithmic_bytes_per_sample": b_sample,
+                     "note": "achieved = HBM bytes of one device's pipeline pass / its duration (HIP events on the launch stream). "
+                             "The path state streamed between the phase kernels IS the traffic; the scene (object list, BVH) is "
+                             "SGPR/LDS/L2-resident, so SURVEY 8(d)'s logical bytes are informational only. valu_issue_frac = "
+                             "SQ_INSTS_VALU x 2 cycles / (1024 SIMDs x 2.4 GHz x kernel time); valu_lane_frac = valu_issue_frac x "
+                             "active lanes / 64 (committed PMC of the same kernel sources only)"},
+    }
+    if extra_config:
+        out["config"].update(extra_config)
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(sc, flat)
+    print(json.dumps(out), flush=True)
+
+
+def run_in_process(args):
+    """N GPUs of this node from ONE process, through the product's own multi-GPU entry point (mi_multi_*: one context,
+    stream and host thread per device inside the library, native RCCL send/recv fan-in to device 0, K3 + K4 there) —
+    what a Rust caller's `render_to_image` (tracing.rs:221) would call.  No launcher, no torch: every output pointer is
+    NULL, so the finished f32 and u8 images stay resident on device 0 and nothing crosses PCIe in the timed region."""
+    from cs397raytracingsp22_amd import MultiContext
+    sc = make_scene(args.config)
+    if args.spp:
+        sc.camera.aa_sample_count = args.spp
+    cam = sc.camera
+    flat = sc.flatten()
+    m = MultiContext(args.gpus)            # fails loudly (MI_ERR_INVALID: device out of range) when the node has fewer devices
+    try:
+        m.upload(flat)                     # scene resident in HBM (replicated) before the timed region
+        m.reserve(cam)
+        dev0 = m.context(0)
+        for _ in range(args.warmup):
+            m.render(cam, seed=1, want_f32=False, want_u8=False, variant=args.variant, flags=args.flags)
+        pipe = {"wf_main_ms": 0.0, "wf_trav_ms": 0.0, "wf_reduce_ms": 0.0, "launches": 0, "wf_trav_f_ms": 0.0, "wf_replay_ms": 0.0}
+        counts, kms, wall = None, [], []
+        # mi_multi_render is blocking: it returns after every device's stream has drained (the barrier + synchronize of the
+        # contract are inside the call, on both sides of every step)
+        t0 = time.perf_counter()
+        for s in range(args.steps):
+            _, _, _, st = m.render(cam, seed=1 + s, want_f32=False, want_u8=False, variant=args.variant, flags=args.flags)
+            kms.append(st.kernel_ms)       # the slowest device's pipeline pass
+            wall.append(st.total_ms)
+            for k, v in dev0.last_pipeline_ms().items():
+                pipe[k] += v
+            counts = dev0.last_pipeline_counts()
+        dt = time.perf_counter() - t0
+        report(args, sc, flat, args.gpus, "rccl (mi_multi, in-process)", "mi_multi_* in one process (native RCCL fan-in, include/mi_rt.h)",
+               dt, sum(kms) / max(1, len(kms)), pipe, counts,
+               extra_config={"ranks": m.n_devices, "mi_multi_total_ms": sum(wall) / max(1, len(wall))})
+    finally:
+        m.close()
 
 
 def main():
@@ -164,9 +284,18 @@ def main():
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--flags", type=int, default=0, help="mi_render_opts.flags (MI_OPT_*), developer A/B")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--via-multi", action="store_true", help="N = 1 through mi_multi_* as well (the route every N > 1 run without a launcher takes)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     ap.add_argument("--same-gpu", action="store_true", help="rehearsal: every rank uses GPU 0 (with --backend gloo)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+
+    # Two ways to N GPUs.  Under torch.distributed.run (WORLD_SIZE set): one process per GPU, dist.py + torch's RCCL gather.
+    # Without a launcher: N > 1 (or --via-multi) runs in THIS process through mi_multi_* (native RCCL inside the library).
+    launched = "WORLD_SIZE" in os.environ
+    if not launched and (args.gpus > 1 or args.via_multi):
+        return run_in_process(args)
 
     import torch
     import torch.distributed as dist
@@ -177,7 +306,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher set WORLD_SIZE={world}: pass --nproc-per-node {args.gpus}")
     if args.same_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -226,65 +355,10 @@ def main():
     else:
         kernel_ms = sum(r.kernel_ms) / max(1, len(r.kernel_ms))
 
-    samples_per_frame = cam.screen_width * cam.screen_height * cam.aa_sample_count
-    ms_per_step = dt / args.steps * 1e3
-    value = samples_per_frame * args.steps / dt / 1e6
-
     if rank == 0:
-        b_sample, segs = algorithmic_bytes_per_sample(args.config, cam.aa_sample_count)
-        wavefront = args.variant in (0, 7)
-        per_step = {k: (v / args.steps) for k, v in pipe.items()}
-        # ---- HBM roofline of the dominant kernel group (the pipeline pass of this rank) ----
-        pmc, why_not = (committed_pmc(args.config) if world == 1 and not args.spp and wavefront and not args.flags else (None, "not the profiled configuration"))
-        model_bytes = traffic_model(counts, flat.desc.n_meshes) if (wavefront and counts and counts["passes"]) else None
-        if pmc is not None and pmc.get("hbm_bytes_per_launch"):
-            traffic, traffic_source = float(pmc["hbm_bytes_per_launch"]), \
-                f"committed rocprofv3 PMC, profiles/traffic_{args.config}.json tag {pmc['tag']} (same kernel sources {pmc['source_hash']}); not measured in this run"
-        elif model_bytes is not None:
-            traffic, traffic_source = model_bytes, f"traffic model on this run's own path counts ({why_not})"
-        else:
-            traffic, traffic_source = None, why_not
-        achieved = traffic / (kernel_ms * 1e-3) / 1e9 if traffic else None
-        frac = achieved / HBM_PEAK_GBS if achieved is not None else None
-        if frac is not None:
-            assert frac <= 1.0, f"HBM roofline fraction {frac} > 1: traffic accounting is wrong"
-        valu = None
-        if pmc is not None:
-            valu = {k: {"ms": v["ms"], "valu_insts": v["valu_insts"], "issue_frac": v["valu_issue_frac"], "active_lanes": v["active_lanes"],
-                        "hbm_GBps": v["hbm_GBps"]}
-                    for k, v in pmc.get("per_kernel", {}).items() if v.get("valu_insts") or v.get("hbm_bytes")}
-        out = {
-            "metric": "Msamples/sec (=rays/sec) at 1080p Cornell+teapot, 256 spp; 1/2/4/8 GPU",
-            "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic", "backend": (args.backend if world > 1 else None),
-            "config": {"workload": f"{args.config}: {CONFIGS[args.config]}",
-                       "width": cam.screen_width, "height": cam.screen_height, "spp": cam.aa_sample_count,
-                       "path_depth": cam.path_depth, "parallelism": f"tiles32x32_mod{world}",
-                       "caller": "python ctypes over the C ABI (include/mi_rt.h)",
-                       "segments_per_sample": segs, "msegments_per_s": (value * segs if segs else None),
-                       "multi_gpu_note": "N>1 numbers exist only where the driver ran this script on a multi-GPU node; "
-                                         "the builder's own N>1 figures are single-GPU rehearsals (DESIGN.md section 6)"},
-            "roofline": {"bound": "hbm",
-                         "kernel": "K1w pipeline pass (wf_main + wf_prefix + wf_trav per segment, wf_reduce)" if wavefront else "single-launch kernel",
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": frac,
-                         "traffic": traffic, "traffic_source": traffic_source,
-                         "traffic_model_bytes": model_bytes, "path_counts": counts,
-                         "kernel_ms": kernel_ms,
-                         "per_step_ms": ({"wf_main": per_step["wf_main_ms"], "wf_trav": per_step["wf_trav_ms"],
-                                          "wf_reduce": per_step["wf_reduce_ms"], "launches": per_step["launches"],
-                                          "wf_trav_f": per_step["wf_trav_f_ms"], "wf_replay": per_step["wf_replay_ms"]}
-                                         if per_step["launches"] else None),
-                         "valu": valu,
-                         "algorithmic_bytes_per_sample": b_sample,
-                         "note": "achieved = HBM bytes of one pipeline pass / its duration (HIP events on the launch stream). "
-                                 "The path state streamed between the phase kernels IS the traffic; the scene (object list, BVH) is "
-                                 "SGPR/LDS/L2-resident, so SURVEY 8(d)'s logical bytes are informational only. valu.issue_frac = "
-                                 "SQ_INSTS_VALU x 2 cycles / (1024 SIMDs x 2.4 GHz x kernel time)"},
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(sc, flat)
-        print(json.dumps(out), flush=True)
+        report(args, sc, flat, world, (args.backend if world > 1 else None),
+               "one process per GPU (torch.distributed.run), dist.py + torch.distributed.gather" if world > 1 else "one process, one GPU (mi_ctx_*)",
+               dt, kernel_ms, pipe, counts)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -108,7 +108,7 @@ EXPORTS = [
     "mi_ctx_create", "mi_ctx_destroy", "mi_scene_upload", "mi_render", "mi_compact_size",
     "mi_render_tiles_device", "mi_unpermute_device", "mi_tonemap_device", "mi_last_kernel_ms",
     "mi_reserve", "mi_render_samples_device", "mi_last_pipeline_ms", "mi_last_pipeline_counts", "mi_last_diag", "mi_last_error", "mi_abi_version",
-    "mi_multi_create", "mi_multi_destroy", "mi_multi_device_count", "mi_multi_scene_upload", "mi_multi_reserve", "mi_multi_render",
+    "mi_multi_create", "mi_multi_destroy", "mi_multi_device_count", "mi_multi_context", "mi_multi_scene_upload", "mi_multi_reserve", "mi_multi_render",
 ]
 
 _lib = None
@@ -176,6 +176,8 @@ def load() -> C.CDLL:
     lib.mi_multi_destroy.restype = None
     lib.mi_multi_device_count.argtypes = [vp]
     lib.mi_multi_device_count.restype = C.c_int
+    lib.mi_multi_context.argtypes = [vp, C.c_int]
+    lib.mi_multi_context.restype = vp
     lib.mi_multi_scene_upload.argtypes = [vp, C.POINTER(mi_scene_desc)]
     lib.mi_multi_scene_upload.restype = C.c_int
     lib.mi_multi_reserve.argtypes = [vp, C.POINTER(mi_camera_desc), C.c_uint64]

@@ -1405,6 +1405,10 @@ extern "C" int mi_multi_create(int n_devices, const int* devices, mi_multi** out
 }
 
 extern "C" int mi_multi_device_count(const mi_multi* m) { return m ? (int)m->ctx.size() : 0; }
+extern "C" mi_ctx* mi_multi_context(const mi_multi* m, int rank) {
+    if (!m || rank < 0 || (size_t)rank >= m->ctx.size()) { (void)fail(MI_ERR_INVALID, "mi_multi_context: rank %d out of range", rank); return nullptr; }
+    return m->ctx[(size_t)rank];
+}
 
 // Run fn(rank) on one host thread per device; the first failure (code + message) is reported in the caller's thread.
 template <class F> static int on_every_device(mi_multi* m, F fn) {
@@ -1453,7 +1457,7 @@ extern "C" int mi_multi_render(mi_multi* m, const mi_camera_desc* cam, const mi_
     mi_ctx* c0 = m->ctx[0];
     HIP_TRY(hipSetDevice(m->devices[0]));
     if ((rc = ensure((void**)&c0->d_image, &c0->image_bytes, npix * 3 * sizeof(float))) != MI_OK) return rc;
-    if (out_rgb_u8 && (rc = ensure((void**)&c0->d_u8, &c0->u8_bytes, npix * 3)) != MI_OK) return rc;
+    if ((rc = ensure((void**)&c0->d_u8, &c0->u8_bytes, npix * 3)) != MI_OK) return rc;     // K4 always runs: the u8 image stays resident on device 0
     if (want_sig && (rc = ensure(&m->d_sig_image, &m->sig_image_bytes, npix * 4)) != MI_OK) return rc;
 
     // ---- every device renders its tiles (one host thread each; the wavefront pipeline drives its passes from the host) ----
@@ -1473,26 +1477,30 @@ extern "C" int mi_multi_render(mi_multi* m, const mi_camera_desc* cam, const mi_
     if (rc != MI_OK) return rc;
 
     // ---- the frame's single exchange: fan-in of the compact buffers to device 0 (one group, issued from this thread) ----
+    // A failure between GroupStart and GroupEnd must not leave the group open (every later RCCL call of this thread would
+    // silently join it): the first error is kept, the remaining calls of the group are skipped, GroupEnd always runs.
     if (world > 1) {
+        ncclResult_t first = ncclSuccess; const char* what = "";
+        auto step = [&](ncclResult_t r, const char* name) { if (first == ncclSuccess && r != ncclSuccess) { first = r; what = name; } return first == ncclSuccess; };
         RCCL_TRY(g_rccl.GroupStart());
         for (int r = 1; r < world; r++) {
-            RCCL_TRY(g_rccl.Recv((float*)m->d_compact[0] + (size_t)r * slice_f, slice_f, ncclFloat, r, m->comm[0], c0->stream));
-            RCCL_TRY(g_rccl.Send(m->d_compact[(size_t)r], slice_f, ncclFloat, 0, m->comm[(size_t)r], m->ctx[(size_t)r]->stream));
+            if (!step(g_rccl.Recv((float*)m->d_compact[0] + (size_t)r * slice_f, slice_f, ncclFloat, r, m->comm[0], c0->stream), "ncclRecv")) break;
+            if (!step(g_rccl.Send(m->d_compact[(size_t)r], slice_f, ncclFloat, 0, m->comm[(size_t)r], m->ctx[(size_t)r]->stream), "ncclSend")) break;
             if (want_sig) {
-                RCCL_TRY(g_rccl.Recv((uint32_t*)m->d_sig[0] + (size_t)r * slice_s, slice_s, ncclUint32, r, m->comm[0], c0->stream));
-                RCCL_TRY(g_rccl.Send(m->d_sig[(size_t)r], slice_s, ncclUint32, 0, m->comm[(size_t)r], m->ctx[(size_t)r]->stream));
+                if (!step(g_rccl.Recv((uint32_t*)m->d_sig[0] + (size_t)r * slice_s, slice_s, ncclUint32, r, m->comm[0], c0->stream), "ncclRecv (signatures)")) break;
+                if (!step(g_rccl.Send(m->d_sig[(size_t)r], slice_s, ncclUint32, 0, m->comm[(size_t)r], m->ctx[(size_t)r]->stream), "ncclSend (signatures)")) break;
             }
         }
-        RCCL_TRY(g_rccl.GroupEnd());
+        const ncclResult_t e_end = g_rccl.GroupEnd();
+        if (first != ncclSuccess) return fail(MI_ERR_HIP, "%s failed inside the frame's exchange: %s", what, g_rccl.GetErrorString(first));
+        if (e_end != ncclSuccess) return fail(MI_ERR_HIP, "ncclGroupEnd failed: %s", g_rccl.GetErrorString(e_end));
     }
     // ---- K3 + K4 on device 0, in stream order behind the receives ----
     HIP_TRY(hipSetDevice(m->devices[0]));
     HIP_TRY(launch_unpermute((const float*)m->d_compact[0], c0->d_image, cam->screen_width, cam->screen_height, tx, (uint32_t)world, padded, c0->stream));
     if (out_rgb_f32) HIP_TRY(hipMemcpyAsync(out_rgb_f32, c0->d_image, npix * 3 * sizeof(float), hipMemcpyDeviceToHost, c0->stream));
-    if (out_rgb_u8) {
-        HIP_TRY(launch_tonemap(c0->d_image, c0->d_u8, (uint32_t)npix, 1.0f / cam->gamma, c0->stream));
-        HIP_TRY(hipMemcpyAsync(out_rgb_u8, c0->d_u8, npix * 3, hipMemcpyDeviceToHost, c0->stream));
-    }
+    HIP_TRY(launch_tonemap(c0->d_image, c0->d_u8, (uint32_t)npix, 1.0f / cam->gamma, c0->stream));
+    if (out_rgb_u8) HIP_TRY(hipMemcpyAsync(out_rgb_u8, c0->d_u8, npix * 3, hipMemcpyDeviceToHost, c0->stream));
     if (want_sig) {
         HIP_TRY(launch_sig_unpermute((const uint32_t*)m->d_sig[0], (uint32_t*)m->d_sig_image, cam->screen_width, cam->screen_height, tx, (uint32_t)world, padded, c0->stream));
         HIP_TRY(hipMemcpyAsync(out_sig, m->d_sig_image, npix * 4, hipMemcpyDeviceToHost, c0->stream));

@@ -62,16 +62,20 @@ class Camera:                        # tracing.rs:138-155, same fields
 class Context:
     """One mi_ctx = one GPU (one process per GPU: pass LOCAL_RANK)."""
 
-    def __init__(self, device: int = 0):
+    def __init__(self, device: int = 0, _borrowed=None):
         self._lib = abi.load()
         self._h = C.c_void_p()
-        abi.check(self._lib.mi_ctx_create(device, C.byref(self._h)))
+        self._owned = _borrowed is None
+        if _borrowed is None:
+            abi.check(self._lib.mi_ctx_create(device, C.byref(self._h)))
+        else:                                  # a device context owned by a MultiContext (mi_multi_context)
+            self._h = C.c_void_p(_borrowed)
         self.device = device
 
     def close(self):
-        if self._h:
+        if self._h and self._owned:
             self._lib.mi_ctx_destroy(self._h)
-            self._h = C.c_void_p()
+        self._h = C.c_void_p()
 
     def __del__(self):
         try:
@@ -194,15 +198,23 @@ class MultiContext:
     def upload(self, flat: FlatScene):
         abi.check(self._lib.mi_multi_scene_upload(self._h, C.byref(flat.desc)))
 
+    def context(self, rank: int) -> Context:
+        """The context of device number `rank`, borrowed (mi_multi_context): per-device timing and path counts."""
+        h = self._lib.mi_multi_context(self._h, rank)
+        if not h:
+            abi.check(abi.MI_ERR_INVALID)
+        return Context(rank, _borrowed=h)
+
     def reserve(self, cam: Camera, max_state_bytes: int = 0):
         pod = cam.to_pod()
         abi.check(self._lib.mi_multi_reserve(self._h, C.byref(pod), max_state_bytes))
 
     def render(self, cam: Camera, seed: int = 1, want_f32=True, want_u8=True, want_sig=False, flags: int = 0,
-               max_state_bytes: int = 0):
-        """mi_multi_render: the whole image, assembled on device 0.  Same return value as Context.render."""
+               max_state_bytes: int = 0, variant: int = abi.MI_VARIANT_DEFAULT):
+        """mi_multi_render: the whole image, assembled on device 0.  Same return value as Context.render.  With no output
+        wanted the finished f32 and u8 images stay resident on device 0 (nothing crosses PCIe)."""
         pod = cam.to_pod()
-        opts = abi.mi_render_opts(seed=seed, rank=0, world=1, variant=abi.MI_VARIANT_DEFAULT, want_signature=int(want_sig),
+        opts = abi.mi_render_opts(seed=seed, rank=0, world=1, variant=variant, want_signature=int(want_sig),
                                   flags=flags, max_state_bytes=max_state_bytes)
         H, W = cam.screen_height, cam.screen_width
         f32 = np.empty((H, W, 3), np.float32) if want_f32 else None

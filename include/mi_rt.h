@@ -294,13 +294,17 @@ int  mi_last_diag(mi_ctx* ctx, uint64_t* out16);
  * One mi_multi owns one context, stream and (per frame) one host thread per device.  The image is cut into MI_TILE^2 tiles,
  * tile t rendered on device t % N; per frame there is exactly ONE exchange — every peer sends its compact tile buffer to
  * device 0 over its own xGMI link (RCCL ncclSend / ncclRecv in one group, resolved with dlopen at mi_multi_create) — then the
- * un-permute and the tone-map run on device 0.  The image is bit-identical for every N (the RNG is keyed by the global
- * pixel index).  `devices` = NULL means 0 .. n_devices-1.  mi_multi_render: as mi_render; opts->rank / world are ignored;
+ * un-permute and the tone-map run on device 0 — always, so a call with all three output pointers NULL leaves the finished
+ * f32 and u8 images resident on device 0 and moves nothing over PCIe.  The image is bit-identical for every N (the RNG is
+ * keyed by the global pixel index).  `devices` = NULL means 0 .. n_devices-1.  mi_multi_render: as mi_render; opts->rank / world are ignored;
  * stats->kernel_ms is the slowest device's pipeline pass, stats->total_ms the wall time of the call. */
 typedef struct mi_multi mi_multi;
 int  mi_multi_create(int n_devices, const int* devices, mi_multi** out);
 void mi_multi_destroy(mi_multi* m);
 int  mi_multi_device_count(const mi_multi* m);
+/* The context of device number `rank` (0 .. N-1), owned by `m` and valid until mi_multi_destroy: for the per-device queries
+ * (mi_last_kernel_ms, mi_last_pipeline_ms, mi_last_pipeline_counts) after a mi_multi_render.  NULL if out of range. */
+mi_ctx* mi_multi_context(const mi_multi* m, int rank);
 int  mi_multi_scene_upload(mi_multi* m, const mi_scene_desc* scene);
 int  mi_multi_reserve(mi_multi* m, const mi_camera_desc* cam, uint64_t max_state_bytes);
 int  mi_multi_render(mi_multi* m, const mi_camera_desc* cam, const mi_render_opts* opts,

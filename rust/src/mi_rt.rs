@@ -62,6 +62,7 @@ extern "C" {
     pub fn mi_multi_create(n_devices: c_int, devices: *const c_int, out: *mut *mut mi_multi) -> c_int;
     pub fn mi_multi_destroy(m: *mut mi_multi);
     pub fn mi_multi_device_count(m: *const mi_multi) -> c_int;
+    pub fn mi_multi_context(m: *const mi_multi, rank: c_int) -> *mut mi_ctx;
     pub fn mi_multi_scene_upload(m: *mut mi_multi, scene: *const mi_scene_desc) -> c_int;
     pub fn mi_multi_reserve(m: *mut mi_multi, cam: *const mi_camera_desc, max_state_bytes: u64) -> c_int;
     pub fn mi_multi_render(m: *mut mi_multi, cam: *const mi_camera_desc, opts: *const mi_render_opts,

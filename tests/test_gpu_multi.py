@@ -86,3 +86,48 @@ def test_torch_nccl_gather_world2():
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     rec = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
     assert rec["n_gpus"] == 2 and rec["backend"] == "nccl" and rec["value"] > 0
+
+
+def _run_bench(*extra, timeout=900):
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}      # no launcher
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), *extra], capture_output=True, text=True,
+                         timeout=timeout, cwd=root, env=env)
+    rec = None
+    for ln in out.stdout.splitlines():
+        if ln.startswith("{"):
+            rec = json.loads(ln)
+    return out, rec
+
+
+def test_bench_in_process_route_one_device():
+    """`python bench.py --gpus 1 --via-multi`: the route every N > 1 run without a launcher takes (mi_multi_* in this process,
+    no torch), on the one device this box has.  (Bit-identity of that route with mi_render: the first test of this file.)"""
+    out, rec = _run_bench("--gpus", "1", "--via-multi", "--steps", "2", "--warmup", "1", "--spp", "16", "--no-cpu-baseline")
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert rec["n_gpus"] == 1 and rec["backend"].startswith("rccl (mi_multi") and rec["config"]["ranks"] == 1
+    assert rec["value"] > 0 and rec["roofline"]["frac"] is not None and 0 < rec["roofline"]["frac"] <= 1
+    assert rec["roofline"]["path_counts"]["passes"] > 0 and rec["steps"] == 2 and rec["warmup"] == 1
+
+
+def test_bench_more_gpus_than_devices_fails_loudly():
+    """`python bench.py --gpus N` with N > devices: mi_multi_create's own error and a non-zero exit — not a hint to use a launcher,
+    not a silent N = 1 run."""
+    n = _devices() + 1
+    out, rec = _run_bench("--gpus", str(n), "--steps", "1", "--warmup", "0", "--spp", "16", "--no-cpu-baseline", timeout=300)
+    assert out.returncode != 0 and rec is None
+    assert "out of range" in out.stderr and "torch.distributed.run" not in out.stderr
+
+
+@pytest.mark.parametrize("n", [2, 4, 8])
+def test_bench_in_process_n_devices(n):
+    """The scaling bench exactly as `python bench.py --gpus N` runs it with no launcher: native RCCL fan-in inside mi_multi_render."""
+    if _devices() < n:
+        pytest.skip(f"needs {n} GPUs, this box has {_devices()}")
+    out, rec = _run_bench("--gpus", str(n), "--steps", "2", "--warmup", "1", "--spp", "64", "--no-cpu-baseline")
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert rec["n_gpus"] == n and rec["config"]["ranks"] == n and rec["backend"].startswith("rccl (mi_multi") and rec["value"] > 0
