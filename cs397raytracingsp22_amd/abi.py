@@ -107,7 +107,7 @@ class mi_stats(C.Structure):
 EXPORTS = [
     "mi_ctx_create", "mi_ctx_destroy", "mi_scene_upload", "mi_render", "mi_compact_size",
     "mi_render_tiles_device", "mi_unpermute_device", "mi_tonemap_device", "mi_last_kernel_ms",
-    "mi_reserve", "mi_render_samples_device", "mi_last_pipeline_ms", "mi_last_pipeline_counts", "mi_last_diag", "mi_last_error", "mi_abi_version",
+    "mi_reserve", "mi_render_samples_device", "mi_last_pipeline_ms", "mi_last_pipeline_counts", "mi_last_diag", "mi_selftest", "mi_last_error", "mi_abi_version",
     "mi_multi_create", "mi_multi_destroy", "mi_multi_device_count", "mi_multi_context", "mi_multi_scene_upload", "mi_multi_reserve", "mi_multi_render",
 ]
 
@@ -170,6 +170,8 @@ def load() -> C.CDLL:
     lib.mi_last_pipeline_counts.restype = C.c_int
     lib.mi_last_diag.argtypes = [vp, C.POINTER(C.c_uint64)]
     lib.mi_last_diag.restype = C.c_int
+    lib.mi_selftest.argtypes = [vp, C.POINTER(C.c_uint64)]
+    lib.mi_selftest.restype = C.c_int
     lib.mi_multi_create.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(vp)]
     lib.mi_multi_create.restype = C.c_int
     lib.mi_multi_destroy.argtypes = [vp]

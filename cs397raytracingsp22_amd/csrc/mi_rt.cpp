@@ -50,6 +50,7 @@ hipError_t launch_unpermute(const float* gathered, float* image, uint32_t width,
 hipError_t launch_sig_unpermute(const uint32_t* gathered, uint32_t* image, uint32_t width, uint32_t height,
                                 uint32_t tiles_x, uint32_t world, uint32_t tiles_padded, hipStream_t stream);
 hipError_t launch_tonemap(const float* image, uint8_t* out, uint32_t n_pixels, float inv_gamma, hipStream_t stream);
+hipError_t launch_selftest_rcp(unsigned long long* d_mismatches, hipStream_t stream);
 }  // namespace pt
 
 using namespace pt;
@@ -1257,6 +1258,19 @@ extern "C" int mi_last_diag(mi_ctx* c, uint64_t* out16) {
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(out16, c->d_diag, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return MI_OK;
+}
+
+extern "C" int mi_selftest(mi_ctx* c, uint64_t* out4) {
+    if (!c || !out4) return fail(MI_ERR_INVALID, "mi_selftest: bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    for (int k = 0; k < 4; k++) out4[k] = 0;
+    HIP_TRY(hipMemsetAsync(c->d_diag, 0, 16 * sizeof(unsigned long long), c->stream));
+    HIP_TRY(launch_selftest_rcp(c->d_diag, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    unsigned long long bad = 0;
+    HIP_TRY(hipMemcpy(&bad, c->d_diag, sizeof bad, hipMemcpyDeviceToHost));
+    out4[0] = bad; out4[1] = 1ull << 32;
     return MI_OK;
 }
 

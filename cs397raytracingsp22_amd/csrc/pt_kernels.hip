@@ -81,8 +81,52 @@ __device__ __forceinline__ f3 cross(f3 a, f3 b) {
     return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
 }
 __device__ __forceinline__ float mag2(f3 a) { return dot(a, a); }
+// Correctly rounded 1.0f / x in 5 VALU instructions instead of the 11 of hipcc's IEEE division sequence (v_div_scale x2,
+// v_rcp, 5 x fma, v_div_fmas, v_div_fixup).  v_rcp_f32 (1 ulp) followed by ONE Newton step in fused arithmetic is the
+// correctly rounded reciprocal for EVERY f32 whose biased exponent lies in [2, 252] — checked exhaustively on gfx950, all
+// 2^32 bit patterns, 0 mismatches against `1.0f / x` (tools/exhaustive/rcp_check.hip; the library re-runs that sweep as
+// mi_selftest, tests/test_gpu_selftest.py).  Outside that range (zeros, denormals, |x| < 2^-125 or >= 2^126, inf, NaN) the
+// IEEE sequence runs under an exec mask that is almost never taken.  The explicit fmaf calls are not contractions: the
+// result is bit-identical to the division the reference (and the oracle) performs, for every input.
+__device__ __forceinline__ float rcp_exact(float x) {
+#if defined(PT_RCP_IEEE)
+    return 1.0f / x;
+#else
+    const float ax = fabsf(x);
+    float r = __builtin_amdgcn_rcpf(x);
+    const float e = __builtin_fmaf(-x, r, 1.0f);
+    r = __builtin_fmaf(e, r, r);
+    const bool out_of_range = !((ax >= 2.3509887e-38f) & (ax < 8.5070592e37f));     // NOT 2^-125 <= |x| < 2^126  <=>  biased exponent outside [2, 252]
+#if defined(PT_RCP_LANE_BRANCH)
+    if (out_of_range) r = 1.0f / x;
+#else
+    // wave-uniform fallback: one scalar branch that is almost never taken (no exec-mask bookkeeping on the hot path)
+    if (__builtin_amdgcn_ballot_w64(out_of_range) != 0ull) r = out_of_range ? 1.0f / x : r;
+#endif
+    return r;
+#endif
+}
+// three reciprocals (inv_d of a slab walk, geometry.rs:57) behind ONE range check and one never-taken scalar branch
+__device__ __forceinline__ void rcp3_exact(float x, float y, float z, float& rx, float& ry, float& rz) {
+#if defined(PT_RCP_IEEE)
+    rx = 1.0f / x; ry = 1.0f / y; rz = 1.0f / z;
+#else
+    float a = __builtin_amdgcn_rcpf(x), b = __builtin_amdgcn_rcpf(y), c = __builtin_amdgcn_rcpf(z);
+    a = __builtin_fmaf(__builtin_fmaf(-x, a, 1.0f), a, a);
+    b = __builtin_fmaf(__builtin_fmaf(-y, b, 1.0f), b, b);
+    c = __builtin_fmaf(__builtin_fmaf(-z, c, 1.0f), c, c);
+    // all three inside [2^-125, 2^126)  <=>  min |.| >= 2^-125 and max |.| < 2^126 (a NaN operand makes one of the two compares false)
+    const float lo = fminf(fminf(fabsf(x), fabsf(y)), fabsf(z)), hi = fmaxf(fmaxf(fabsf(x), fabsf(y)), fabsf(z));
+    const bool nan = (x != x) | (y != y) | (z != z);
+    const bool out_of_range = nan | !((lo >= 2.3509887e-38f) & (hi < 8.5070592e37f));
+    if (__builtin_amdgcn_ballot_w64(out_of_range) != 0ull) {      // axis-parallel rays (a zero component) come here: IEEE for the whole wave
+        a = 1.0f / x; b = 1.0f / y; c = 1.0f / z;
+    }
+    rx = a; ry = b; rz = c;
+#endif
+}
 // InnerSpace::normalize = self * (1 / magnitude)
-__device__ __forceinline__ f3 normalize(f3 a) { return a * (1.0f / sqrtf(mag2(a))); }
+__device__ __forceinline__ f3 normalize(f3 a) { return a * rcp_exact(sqrtf(mag2(a))); }
 // Matrix3 * Vector3, column-major m[9]
 __device__ __forceinline__ f3 m3mul(const float* m, f3 v) {
     return mk3((m[0] * v.x + m[3] * v.y) + m[6] * v.z,
@@ -225,7 +269,7 @@ __device__ __forceinline__ f3 rotate_from_unit_y(f3 n, f3 dir) {
         float s = k + k_cos_theta;
         float cx = n.z, cz = -n.x;
         float mag = sqrtf(s * s + ((cx * cx + 0.0f) + cz * cz));
-        float inv = 1.0f / mag;
+        float inv = rcp_exact(mag);
         qs = s * inv; qx = cx * inv; qz = cz * inv;
     }
     float x2 = qx + qx, z2 = qz + qz;
@@ -263,11 +307,13 @@ __device__ __forceinline__ bool sphere_t(f3 o, f3 d, f3 center, float r2, float 
 }
 
 // Triangle / IndexedTriangle Moller-Trumbore geometry.rs:331-349, 431-447
+// FAST = false: the IEEE division for 1/g (the 1024-thread walker is LDS-bound, the short reciprocal's range check only costs there)
+template <bool FAST = true>
 __device__ __forceinline__ bool tri_t(f3 o, f3 d, f3 a, f3 e1, f3 e2, float t_min, float t_max,
                                       float& t_out, float& u_out, float& v_out) {
     f3 q = cross(d, e2);
     float g = dot(e1, q);
-    float f = 1.0f / g;
+    float f = FAST ? rcp_exact(g) : 1.0f / g;
     f3 s = o - a;
     float u = f * dot(s, q);
     f3 r = cross(s, e1);
@@ -384,7 +430,7 @@ template <class BVH>
 __device__ __forceinline__ void traverse_mesh(const BVH& B, int node_begin, int node_end, int tri_begin,
                                               f3 o, f3 d, float t_min, float t_max,
                                               float& best_t, int& best_tri, float& best_u, float& best_v) {
-    f3 inv_d = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);       // geometry.rs:57
+    f3 inv_d; rcp3_exact(d.x, d.y, d.z, inv_d.x, inv_d.y, inv_d.z);      // geometry.rs:57
     best_t = t_max; best_tri = -1; best_u = 0.0f; best_v = 0.0f;
     int i = node_begin;
     while (i < node_end) {
@@ -1094,7 +1140,7 @@ __device__ __forceinline__ bool enter_next_mesh(const DScene& S, const BVH& B, i
         auto M = &S.meshes[m];
         oo = xform_point(M->inv_transform, o);                           // geometry.rs:304
         od = xform_vector(M->inv_transform, d);
-        inv_d = mk3(1.0f / od.x, 1.0f / od.y, 1.0f / od.z);              // geometry.rs:57
+        rcp3_exact(od.x, od.y, od.z, inv_d.x, inv_d.y, inv_d.z);         // geometry.rs:57
         float4 n0, n1;
         B.node(M->node_begin, n0, n1);
         tend = M->node_end; ttb = M->tri_begin;
@@ -1743,7 +1789,7 @@ __global__ __launch_bounds__(BS, (BS == 256 ? PT_TRAV_WAVES : 4)) void wf_trav(W
                     float4 ev;
                     if (LDS != 0) ev = k1_lds[lds_nn + te2 + ltri]; else ev = ((cf4_ptr)S.e2s)[te2 + ltri];
                     float t, u, v;
-                    bool ok = tri_t(too, tod, mk3(c0.x, c0.y, c0.z), mk3(c1.x, c1.y, c1.z), mk3(ev.x, ev.y, ev.z), t_min, tbt, t, u, v);
+                    bool ok = tri_t<BS == 256>(too, tod, mk3(c0.x, c0.y, c0.z), mk3(c1.x, c1.y, c1.z), mk3(ev.x, ev.y, ev.z), t_min, tbt, t, u, v);
                     tbt = ok ? t : tbt; tbtri = ok ? ltri : tbtri; tbu = ok ? u : tbu; tbv = ok ? v : tbv;
                     ti = ti + 1;
                     B.node(min(ti, last_node), c0, c1);
@@ -1848,7 +1894,7 @@ __device__ __forceinline__ bool enter_next_mesh_f(const DScene& S, int& m, uint3
         auto M = &S.meshes[m];
         oo = xform_point(M->inv_transform, o);                           // geometry.rs:304
         od = xform_vector(M->inv_transform, d);
-        inv_d = mk3(1.0f / od.x, 1.0f / od.y, 1.0f / od.z);              // geometry.rs:57
+        rcp3_exact(od.x, od.y, od.z, inv_d.x, inv_d.y, inv_d.z);         // geometry.rs:57
         const float4 n0 = gn[2 * M->node_begin], n1 = gn[2 * M->node_begin + 1];
         if (__float_as_int(n1.w) < 0 &&                                   // a root that is a leaf is never box-tested (:95)
             !slab(mk3(n0.x, n0.y, n0.z), mk3(n1.x, n1.y, n1.z), oo, inv_d, t_min, t_max)) continue;
@@ -2084,7 +2130,7 @@ __global__ __launch_bounds__(256) void wf_replay(WfArgs A) {
                 cur = m;
                 auto M = &S.meshes[m];
                 oo = xform_point(M->inv_transform, o); od = xform_vector(M->inv_transform, d);
-                inv = mk3(1.0f / od.x, 1.0f / od.y, 1.0f / od.z);
+                rcp3_exact(od.x, od.y, od.z, inv.x, inv.y, inv.z);
                 n_tris = M->n_tris; node_begin = M->node_begin;
                 wt = t_max; win = -1; prev = -1; fail_depth = 0x7fffffff;
             }
@@ -2267,7 +2313,24 @@ __global__ __launch_bounds__(256) void fb_tonemap_u8(const float* __restrict__ i
     }
 }
 
+// ---------------------------------------------------------------- self-test of the arithmetic shortcuts
+// rcp_exact against the IEEE division, over ALL 2^32 f32 bit patterns (NaN results compare equal as NaNs).
+__global__ __launch_bounds__(256) void selftest_rcp(unsigned long long* mismatches) {
+    unsigned long long bad = 0;
+    const unsigned long long n = 1ull << 32, stride = (unsigned long long)gridDim.x * blockDim.x;
+    for (unsigned long long i = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float x = __uint_as_float((uint32_t)i);
+        const float a = rcp_exact(x), b = 1.0f / x;
+        if (!(__float_as_uint(a) == __float_as_uint(b) || (a != a && b != b))) bad++;
+    }
+    if (bad) atomicAdd(mismatches, bad);
+}
+
 // ---------------------------------------------------------------- launch wrappers
+hipError_t launch_selftest_rcp(unsigned long long* d_mismatches, hipStream_t stream) {
+    hipLaunchKernelGGL(selftest_rcp, dim3(4096), dim3(256), 0, stream, d_mismatches);
+    return hipGetLastError();
+}
 hipError_t launch_megakernel(const K1Args& args, uint32_t n_blocks, bool lds, bool sig, size_t lds_bytes, hipStream_t stream) {
     dim3 grid(n_blocks), block(kBlock);
 #define PT_LAUNCH(L, G) hipLaunchKernelGGL((pt_megakernel<L, G>), grid, block, (L) ? lds_bytes : 0, stream, args)

@@ -167,6 +167,12 @@ class Context:
              "a_cycles", "b_cycles", "shade_cycles", "gen_cycles", "list_cycles", "slab_tests", "segments"]
         return dict(zip(k, [int(v) for v in out]))
 
+    def selftest(self):
+        """mi_selftest: exhaustive check of the kernels' short reciprocal against the IEEE division -> (mismatches, checked)."""
+        out = (C.c_uint64 * 4)()
+        abi.check(self._lib.mi_selftest(self._h, out))
+        return int(out[0]), int(out[1])
+
     def last_kernel_ms(self) -> float:
         ms = C.c_float()
         abi.check(self._lib.mi_last_kernel_ms(self._h, C.byref(ms)))

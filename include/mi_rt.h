@@ -290,6 +290,13 @@ int  mi_last_pipeline_counts(mi_ctx* ctx, uint64_t* out8);
  * active-lane fraction of a phase = lanes / (64 * trips). */
 int  mi_last_diag(mi_ctx* ctx, uint64_t* out16);
 
+/* Self-test of the kernels' arithmetic shortcuts on this device (about a second).  The kernels compute `1.0 / x` — the
+ * reference's Moller-Trumbore `f = 1.0/a` (geometry.rs:340,437), `inv_d` (geometry.rs:57), cgmath's normalize — with a
+ * 5-instruction sequence (v_rcp_f32 + one fused Newton step, IEEE division outside the exponent range where that is proven)
+ * instead of the 11-instruction IEEE division; this sweeps ALL 2^32 f32 bit patterns and counts the inputs for which the
+ * two differ in any bit.  out4 = { mismatches (must be 0), inputs checked, 0, 0 }. */
+int  mi_selftest(mi_ctx* ctx, uint64_t* out4);
+
 /* ---- multi-GPU behind the ABI: replaces rayon's row split (tracing.rs:228) with N devices of one node ----
  * One mi_multi owns one context, stream and (per frame) one host thread per device.  The image is cut into MI_TILE^2 tiles,
  * tile t rendered on device t % N; per frame there is exactly ONE exchange — every peer sends its compact tile buffer to

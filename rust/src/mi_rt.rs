@@ -58,6 +58,7 @@ extern "C" {
     pub fn mi_last_pipeline_ms(ctx: *mut mi_ctx, out8: *mut f32) -> c_int;
     pub fn mi_last_pipeline_counts(ctx: *mut mi_ctx, out8: *mut u64) -> c_int;
     pub fn mi_last_diag(ctx: *mut mi_ctx, out16: *mut u64) -> c_int;
+    pub fn mi_selftest(ctx: *mut mi_ctx, out4: *mut u64) -> c_int;
     // N GPUs of one node behind one blocking call (RCCL fan-in inside the library)
     pub fn mi_multi_create(n_devices: c_int, devices: *const c_int, out: *mut *mut mi_multi) -> c_int;
     pub fn mi_multi_destroy(m: *mut mi_multi);
