@@ -219,7 +219,8 @@ def report(args, sc, flat, world, backend, route, dt, kernel_ms, pipe, counts, e
                      "kernel_ms": kernel_ms,
                      "per_step_ms": ({"wf_main": per_step["wf_main_ms"], "wf_trav": per_step["wf_trav_ms"],
                                       "wf_reduce": per_step["wf_reduce_ms"], "launches": per_step["launches"],
-                                      "wf_trav_f": per_step["wf_trav_f_ms"], "wf_replay": per_step["wf_replay_ms"]}
+                                      "wf_trav_f": per_step["wf_trav_f_ms"], "wf_replay": per_step["wf_replay_ms"],
+                                      "wf_main_class_a_beside_walkers": per_step["wf_main_a_ms"]}
                                      if per_step.get("launches") else None),
                      "valu": valu,
                      "algorithmic_bytes_per_sample": b_sample,
@@ -254,7 +255,7 @@ def run_in_process(args):
         dev0 = m.context(0)
         for _ in range(args.warmup):
             m.render(cam, seed=1, want_f32=False, want_u8=False, variant=args.variant, flags=args.flags)
-        pipe = {"wf_main_ms": 0.0, "wf_trav_ms": 0.0, "wf_reduce_ms": 0.0, "launches": 0, "wf_trav_f_ms": 0.0, "wf_replay_ms": 0.0}
+        pipe = {"wf_main_ms": 0.0, "wf_trav_ms": 0.0, "wf_reduce_ms": 0.0, "launches": 0, "wf_trav_f_ms": 0.0, "wf_replay_ms": 0.0, "wf_main_a_ms": 0.0}
         counts, kms, wall = None, [], []
         # mi_multi_render is blocking: it returns after every device's stream has drained (the barrier + synchronize of the
         # contract are inside the call, on both sides of every step)
@@ -336,7 +337,7 @@ def main():
         r.render_frame(seed=1)
     barrier()
     t0 = time.perf_counter()
-    pipe = {"wf_main_ms": 0.0, "wf_trav_ms": 0.0, "wf_reduce_ms": 0.0, "launches": 0, "wf_trav_f_ms": 0.0, "wf_replay_ms": 0.0}
+    pipe = {"wf_main_ms": 0.0, "wf_trav_ms": 0.0, "wf_reduce_ms": 0.0, "launches": 0, "wf_trav_f_ms": 0.0, "wf_replay_ms": 0.0, "wf_main_a_ms": 0.0}
     counts = None
     for s in range(args.steps):
         r.render_frame(seed=1 + s, time_kernel=True)

@@ -89,6 +89,8 @@ inline uint32_t lowbias32(uint32_t x) {
 struct mi_ctx {
     int device = 0;
     hipStream_t stream = nullptr;            // own stream for mi_render
+    hipStream_t aux_stream = nullptr;        // wavefront pipeline: the class-A part of a pass runs here, beside the walkers of the previous pass
+    hipEvent_t ev_pfx = nullptr, ev_part = nullptr;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     bool ev_recorded = false;
 
@@ -120,7 +122,7 @@ struct mi_ctx {
     void* d_wf_samp = nullptr; size_t wf_samp_bytes = 0;
     void* d_wf_acc = nullptr; size_t wf_acc_bytes = 0;
     uint32_t* d_wf_cnt = nullptr;
-    uint32_t* h_hdr = nullptr;                       // pinned + device-mapped, 8 words: wf_prefix writes {blocks, live, queue, seq, live class B}
+    uint32_t* h_hdr = nullptr;                       // pinned + device-mapped ring of 8-word slots: wf_prefix writes {blocks, live, queue, seq, live class B, class-A blocks}
     uint64_t wf_counts[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };   // last frame: passes, class-A paths streamed, class-B paths, queue entries, samples, pixels
     uint32_t* h_hdr_dev = nullptr;                   // its device-side address
     uint32_t hdr_seq = 0;
@@ -147,6 +149,8 @@ struct mi_ctx {
         bool wf_stamps = false;                         // -DPT_WF_STAMPS builds: collect wf_main phase stamps
         bool debug_mask = false;                        // print tile-mask statistics
         bool dump_launches = false;                     // print every pipeline launch's duration (needs per-launch events)
+        int split = 1;                                  // wf_main in two parts, class A beside the previous pass' walkers (0 = one launch per pass)
+        uint32_t nowait_blocks = 16384;                 // passes whose grid bound is at most this many blocks are launched without waiting for the previous header (0 = always wait)
         uint32_t spin_timeout_ms = 120000;              // header wait: give up after this long without progress
     } tune;
 };
@@ -167,6 +171,9 @@ extern "C" void mi_ctx_destroy(mi_ctx* c);
 
 static int ctx_init(mi_ctx* c, const hipDeviceProp_t& prop) {
     HIP_TRY(hipStreamCreate(&c->stream));
+    HIP_TRY(hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_pfx, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_part, hipEventDisableTiming));
     HIP_TRY(hipEventCreate(&c->ev_start));
     HIP_TRY(hipEventCreate(&c->ev_stop));
     HIP_TRY(hipEventCreate(&c->ev_t0));
@@ -174,8 +181,8 @@ static int ctx_init(mi_ctx* c, const hipDeviceProp_t& prop) {
     HIP_TRY(hipMalloc((void**)&c->d_diag, 16 * sizeof(unsigned long long)));
     c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     HIP_TRY(hipMalloc((void**)&c->d_wf_cnt, (9 * 256 + 64) * sizeof(uint32_t)));
-    HIP_TRY(hipHostMalloc((void**)&c->h_hdr, 8 * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent));
-    memset(c->h_hdr, 0, 8 * sizeof(uint32_t));
+    HIP_TRY(hipHostMalloc((void**)&c->h_hdr, 16 * 8 * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent));     // kHdrRing slots of 8 words
+    memset(c->h_hdr, 0, 16 * 8 * sizeof(uint32_t));
     HIP_TRY(hipHostGetDevicePointer((void**)&c->h_hdr_dev, c->h_hdr, 0));
     // developer knobs: read here, once (never on the render path)
     mi_ctx::Tuning& t = c->tune;
@@ -185,6 +192,7 @@ static int ctx_init(mi_ctx* c, const hipDeviceProp_t& prop) {
     if (const char* e = getenv("MI_RT_LDS_PAD_KB")) t.lds_pad = (uint32_t)atoi(e) * 1024u;
     env_u("MI_RT_WF_REFILL", t.refill_min);
     env_u("MI_RT_WF_FUSE_MAX", t.fuse_max); env_u("MI_RT_WF_FUSE_MIN", t.fuse_min);
+    env_i("MI_RT_WF_SPLIT", t.split); env_u("MI_RT_WF_NOWAIT_BLOCKS", t.nowait_blocks);
     env_i("MI_RT_WF_TRAV_LDS", t.trav_lds); env_i("MI_RT_WF_TRAV_BPC", t.trav_bpc); env_i("MI_RT_WF_KERNEL_TIMING", t.kernel_timing);
     t.global_bvh = getenv("MI_RT_GLOBAL_BVH") != nullptr;
     t.wf_stamps = getenv("MI_RT_WF_STAMPS") != nullptr;
@@ -251,6 +259,9 @@ extern "C" void mi_ctx_destroy(mi_ctx* c) {
     if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
     if (c->ev_t0) (void)hipEventDestroy(c->ev_t0);
     if (c->ev_t1) (void)hipEventDestroy(c->ev_t1);
+    if (c->ev_pfx) (void)hipEventDestroy(c->ev_pfx);
+    if (c->ev_part) (void)hipEventDestroy(c->ev_part);
+    if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -697,7 +708,9 @@ static void make_camera(const mi_camera_desc* cam, DCamera* C) {
 // Memory: path state is streamed through HBM — 2 x 96 B (ping/pong) + 4 B queue + 16 B sample
 // slot per path.  The batch is sized to the free HBM (288 GB on MI355X: the whole 1080p/256 spp
 // frame, 531 M paths = 112 GB, is ONE batch), halved on allocation failure.
-static const size_t kWfBytesPerPath = 2 * (size_t)kWfPlanes * sizeof(float4) + 4 + sizeof(float4);
+static const int kHdrRing = 16;        // pinned header slots (wf_prefix -> host), one per pass in flight
+static const int kRunAhead = 3;        // passes the host may launch before it has read the header of an earlier one
+static const size_t kWfBytesPerPath = 2 * (size_t)kWfPlanes * sizeof(float4) + 2 * 4 + sizeof(float4);      // ping / pong state, two queues, sample slot
 static const size_t kWfBytesPerPathTwoStage = (size_t)kCandMax * sizeof(uint2) + sizeof(uint2);     // candidates + header per queue slot
 
 // which meshes this render walks two-stage (bit m = live mesh m)
@@ -735,7 +748,7 @@ static int wf_alloc(mi_ctx* c, WfArgs& a, uint32_t spp, uint64_t max_state_bytes
         const size_t st_bytes = (size_t)kWfPlanes * sizeof(float4) * a.cap;
         int rc = ensure(&c->d_wf_a, &c->wf_a_bytes, st_bytes);
         if (rc == MI_OK) rc = ensure(&c->d_wf_b, &c->wf_b_bytes, st_bytes);
-        if (rc == MI_OK) rc = ensure(&c->d_wf_q, &c->wf_q_bytes, (size_t)a.cap * 4);
+        if (rc == MI_OK) rc = ensure(&c->d_wf_q, &c->wf_q_bytes, (size_t)a.cap * 4 * 2);      // queue of pass i is read while pass i + 1 fills the other
         if (rc == MI_OK) rc = ensure(&c->d_wf_samp, &c->wf_samp_bytes, (size_t)paths * sizeof(float4));
         if (rc == MI_OK) rc = ensure(&c->d_wf_acc, &c->wf_acc_bytes, (size_t)a.npix * sizeof(float4));
         if (rc == MI_OK && two_stage) rc = ensure(&c->d_cand, &c->cand_bytes, (size_t)a.cap * kCandMax * sizeof(uint2));
@@ -1006,34 +1019,121 @@ static int render_tiles_wavefront(mi_ctx* c, const K1Args& k, const mi_camera_de
     // of a 1/8 share, so multi-rank renders skip it unless asked (MI_RT_WF_KERNEL_TIMING=0/1 overrides)
     bool per_kernel_timing = a.R.world == 1;
     if (c->tune.kernel_timing >= 0) per_kernel_timing = c->tune.kernel_timing != 0;
-    auto stamp = [&](int kind) -> int {      // kind: 0 wf_main, 1 wf_trav, 2 wf_reduce, 3 wf_trav_f, 4 wf_replay; call before AND after the launch
+    auto stamp = [&](int kind, hipStream_t on) -> int {      // kind: 0 wf_main, 1 wf_trav, 2 wf_reduce, 3 wf_trav_f, 4 wf_replay, 5 wf_main's class-A part on the second stream; call before AND after the launch
         if (!per_kernel_timing) return MI_OK;
         if (ev_used == c->wf_ev.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return MI_ERR_HIP; c->wf_ev.push_back(e); }
-        if (hipEventRecord(c->wf_ev[ev_used++], stream) != hipSuccess) return MI_ERR_HIP;
+        if (hipEventRecord(c->wf_ev[ev_used++], on) != hipSuccess) return MI_ERR_HIP;
         ev_kind.push_back(kind);
         return MI_OK;
     };
-#define WF_TIMED(kind, call) do { if (stamp(kind) != MI_OK) return fail(MI_ERR_HIP, "event"); HIP_TRY(call); if (stamp(kind) != MI_OK) return fail(MI_ERR_HIP, "event"); } while (0)
+#define WF_TIMED_ON(kind, on, call) do { if (stamp(kind, on) != MI_OK) return fail(MI_ERR_HIP, "event"); HIP_TRY(call); if (stamp(kind, on) != MI_OK) return fail(MI_ERR_HIP, "event"); } while (0)
+#define WF_TIMED(kind, call) WF_TIMED_ON(kind, stream, call)
 
     uint64_t counts[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
     counts[4] = (uint64_t)a.npix * (range.end - range.begin); counts[5] = a.npix;
+    const bool have_walkers = ref_mask || ts_mask || c->S.n_meshes > 32;
+    uint32_t* queues[2] = { (uint32_t*)c->d_wf_q, (uint32_t*)c->d_wf_q + a.cap };
+    // Headers: wf_prefix stores {blocks, live paths, queue length, seq, class-B paths, class-A blocks} of every pass into a RING of
+    // pinned host slots (slot = seq % kHdrRing), so the host may run a few passes ahead of the device and still read every header.
+    struct PassHdr { uint32_t blocks, live, queue, live_b, blocks_a; };
+    auto header_ready = [&](uint32_t seq) { return ((volatile uint32_t*)c->h_hdr)[(size_t)(seq % kHdrRing) * 8 + 3] == seq; };
+    auto read_header = [&](uint32_t seq) {
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        const volatile uint32_t* h = (volatile uint32_t*)c->h_hdr + (size_t)(seq % kHdrRing) * 8;
+        PassHdr r = { h[0], h[1], h[2], h[4], h[5] };
+        return r;
+    };
+    auto wait_header = [&](uint32_t seq) -> int {
+        const auto t_wait = std::chrono::steady_clock::now();
+        for (uint32_t spin = 1; !header_ready(seq); spin++) {
+            if ((spin & 63u) == 0) {
+                hipError_t q = hipStreamQuery(stream);
+                if (q == hipSuccess) { if (header_ready(seq)) break; return fail(MI_ERR_HIP, "wavefront pipeline: stream drained without a header"); }
+                if (q != hipErrorNotReady) return fail(MI_ERR_HIP, "wavefront pipeline: %s", hipGetErrorString(q));
+                // a wedged stream neither drains nor errors: bound the wait by wall clock (one pass is milliseconds)
+                const auto waited = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t_wait).count();
+                if (waited > (long long)c->tune.spin_timeout_ms)
+                    return fail(MI_ERR_HIP, "wavefront pipeline: no header from the device after %lld ms (stream wedged?)", (long long)waited);
+            }
+            // the header of a small pass is there within tens of microseconds: poll without sleeping at first (a sleep
+            // costs ~60 us whatever it asks for), then back off
+            if (spin < 4096u && std::chrono::steady_clock::now() - t_wait < std::chrono::microseconds(150)) {
+#if defined(__x86_64__)
+                __builtin_ia32_pause();
+#else
+                std::this_thread::yield();
+#endif
+            } else std::this_thread::sleep_for(std::chrono::microseconds(20));
+        }
+        return MI_OK;
+    };
     for (uint32_t s0 = range.begin; s0 < range.end; s0 += s_batch) {
         a.s_base = s0; a.s_count = (s0 + s_batch <= range.end) ? s_batch : (range.end - s0);
         int cur = 0;
         a.iter0 = 1;
         a.n_in = a.npix * a.s_count;
-        uint32_t n_blocks = (a.n_in + kBlock - 1) / kBlock;
         HIP_TRY(hipMemsetAsync(cnt, 0, (3 * S_ + 8) * sizeof(uint32_t), stream));   // wf_prefix re-zeroes them after every pass
-        for (uint32_t it = 0; it <= cam->path_depth + 1u && n_blocks > 0; it++) {
+        const uint32_t seq0 = c->hdr_seq + 1u;          // seq of this batch's pass 0
+        uint32_t seen = 0;                              // headers of passes [0, seen) have been read
+        PassHdr last = { (a.n_in + kBlock - 1) / kBlock, a.n_in, 0u, 0u, 0u };      // "header of pass -1": the camera rays
+        bool all_dead = false;
+        auto consume = [&](bool count_it) {             // read header `seen` (it has arrived)
+            last = read_header(seq0 + seen);
+            seen++;
+            if (count_it) { counts[0] += 1; counts[1] += last.live - last.live_b; counts[2] += last.live_b; counts[3] += last.queue; }
+            if (last.live == 0) all_dead = true;
+        };
+        uint32_t it = 0;
+        for (; it <= cam->path_depth + 1u; it++) {
+            while (seen < it && !all_dead && header_ready(seq0 + seen)) consume(true);
+            if (all_dead) break;
+            // The grid of pass `it` comes from the header of pass it - 1.  While that pass is still running the host would
+            // have to wait for it (the header is on its way while the walkers run, so for a big pass the wait is hidden); a SMALL
+            // pass is launched at once instead, on a grid that is an upper bound — live paths only decrease, and every (class,
+            // shard) list may end in a partial block — whose surplus blocks leave at their first instruction (wf_main compares
+            // its block number with the device-side table).  The host runs at most kRunAhead passes ahead of the headers.
+            bool exact = seen == it;
+            if (!exact) {
+                const uint64_t bound = (uint64_t)last.live / kBlock + 2u * (uint64_t)kWfShards;
+                if (c->tune.nowait_blocks == 0 || bound > (uint64_t)c->tune.nowait_blocks || it - seen > (uint32_t)kRunAhead) {
+                    while (seen < it && !all_dead) { int rcw = wait_header(seq0 + seen); if (rcw != MI_OK) return rcw; consume(true); }
+                    if (all_dead) break;
+                    exact = true;
+                }
+            }
+            uint32_t grid_all, grid_a;
+            if (exact) { grid_all = last.blocks; grid_a = last.blocks_a; }
+            else { grid_all = grid_a = (uint32_t)((uint64_t)last.live / kBlock) + 2u * (uint32_t)kWfShards; }
+            if (it == 0) { grid_all = last.blocks; grid_a = 0; }
+            if (grid_all == 0) break;
             a.st_in = a.iter0 ? nullptr : bufs[cur];
             a.st_out = bufs[cur ^ 1];
-            a.n_blocks_in = n_blocks;
-            WF_TIMED(0, launch_wf_main(a, n_blocks, d_sig != nullptr, stream));
-            // device-side bookkeeping: tables for the next pass and for wf_trav, and the 3-word header the
-            // host needs (grid of the next pass, anything alive?), which wf_prefix also stores in pinned host
-            // memory: the compute stream never waits for the host
+            a.n_blocks_in = grid_all;
+            a.trav_q = queues[it & 1u];
+            // A pass after the first is launched in TWO PARTS.  Its class-A blocks (paths whose pending hit is a plain Triangle /
+            // Plane: nothing a walker could still change) go to a second stream, ordered only behind the previous pass' wf_prefix:
+            // they fill the CUs the persistent walkers of that pass leave idle as their queue runs out (a walker launch ends
+            // with ~0.1 ms of tail whatever its queue size, eleven times per frame and per rank).  The class-B blocks follow the
+            // walkers on the main stream; wf_prefix waits for both parts.  Same blocks, same work, another schedule.
+            const bool split = !a.iter0 && have_walkers && c->tune.split != 0 && (exact ? (grid_a >= 64u && grid_a < grid_all) : true);
+            if (split) {
+                HIP_TRY(hipStreamWaitEvent(c->aux_stream, c->ev_pfx, 0));
+                a.part = 1;
+                WF_TIMED_ON(5, c->aux_stream, launch_wf_main(a, grid_a, d_sig != nullptr, c->aux_stream));     // kind 5: its span includes waiting for CUs
+                HIP_TRY(hipEventRecord(c->ev_part, c->aux_stream));
+                a.part = 2;
+                WF_TIMED(0, launch_wf_main(a, exact ? grid_all - grid_a : grid_all, d_sig != nullptr, stream));
+                HIP_TRY(hipStreamWaitEvent(stream, c->ev_part, 0));
+            } else {
+                a.part = 0;
+                WF_TIMED(0, launch_wf_main(a, grid_all, d_sig != nullptr, stream));
+            }
+            // device-side bookkeeping: tables for the next pass and for wf_trav, and the header the host needs (grid of the
+            // next pass, anything alive?), which wf_prefix stores straight into pinned host memory: the compute stream never
+            // waits for the host
             const uint32_t seq = ++c->hdr_seq;
-            HIP_TRY(launch_wf_prefix(cnt, cnt + 2 * S_, d_in_count, d_in_pfx, d_trav_pfx, d_hdr, c->h_hdr_dev, seq, stream));
+            HIP_TRY(launch_wf_prefix(cnt, cnt + 2 * S_, d_in_count, d_in_pfx, d_trav_pfx, d_hdr, c->h_hdr_dev + (size_t)(seq % kHdrRing) * 8, seq, stream));
+            if (have_walkers && c->tune.split != 0) HIP_TRY(hipEventRecord(c->ev_pfx, stream));
             // persistent walkers; they leave at once when the queue is empty.  Successive launches merge their meshes' hits
             // into the hit record (strictly closer wins, ties go to the lower Scene.objects index: order-independent)
             if (ref_mask || c->S.n_meshes > 32) {      // meshes 32, 33, ... have no mask bit: they always take the reference walk
@@ -1047,42 +1147,16 @@ static int render_tiles_wavefront(mi_ctx* c, const K1Args& k, const mi_camera_de
                 WF_TIMED(3, launch_wf_trav_f(a, travf_blocks, stream));
                 WF_TIMED(4, launch_wf_replay(a, replay_blocks, stream));
             }
-            // wait for wf_prefix's header (written into pinned host memory) while wf_trav runs
-            {
-                volatile uint32_t* hh = c->h_hdr;
-                const auto t_wait = std::chrono::steady_clock::now();
-                for (uint32_t spin = 1; hh[3] != seq; spin++) {
-                    if ((spin & 63u) == 0) {
-                        hipError_t q = hipStreamQuery(stream);
-                        if (q == hipSuccess) { if (hh[3] == seq) break; return fail(MI_ERR_HIP, "wavefront pipeline: stream drained without a header"); }
-                        if (q != hipErrorNotReady) return fail(MI_ERR_HIP, "wavefront pipeline: %s", hipGetErrorString(q));
-                        // a wedged stream neither drains nor errors: bound the wait by wall clock (one pass is milliseconds)
-                        const auto waited = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t_wait).count();
-                        if (waited > (long long)c->tune.spin_timeout_ms)
-                            return fail(MI_ERR_HIP, "wavefront pipeline: no header from the device after %lld ms (stream wedged?)", (long long)waited);
-                    }
-                    // the header of a small pass is there within tens of microseconds: poll without sleeping at first (a sleep
-                    // costs ~60 us whatever it asks for: nine of them were most of a 400x400 / 16 spp frame), then back off
-                    if (spin < 4096u && std::chrono::steady_clock::now() - t_wait < std::chrono::microseconds(150)) {
-#if defined(__x86_64__)
-                        __builtin_ia32_pause();
-#else
-                        std::this_thread::yield();
-#endif
-                    } else std::this_thread::sleep_for(std::chrono::microseconds(20));
-                }
-                __atomic_thread_fence(__ATOMIC_ACQUIRE);
-            }
-            const uint32_t blk = c->h_hdr[0], n_live = c->h_hdr[1];
-            counts[0] += 1; counts[1] += n_live - c->h_hdr[4]; counts[2] += c->h_hdr[4]; counts[3] += c->h_hdr[2];
-            if (n_live == 0) break;
-            n_blocks = blk;
             cur ^= 1;
             a.iter0 = 0;
         }
         WF_TIMED(2, launch_wf_reduce(a, s0 == 0, s0 + a.s_count >= spp, stream));
+        // the headers not read yet (statistics; passes launched behind the one that ended every path are not counted)
+        const uint32_t launched = c->hdr_seq + 1u - seq0;
+        while (seen < launched) { int rcw = wait_header(seq0 + seen); if (rcw != MI_OK) return rcw; consume(!all_dead); }
     }
 #undef WF_TIMED
+#undef WF_TIMED_ON
     HIP_TRY(hipStreamSynchronize(stream));
     for (int k = 0; k < 8; k++) c->wf_counts[k] = counts[k];
     for (int k = 0; k < 8; k++) c->wf_ms[k] = 0.0f;
@@ -1091,7 +1165,7 @@ static int render_tiles_wavefront(mi_ctx* c, const K1Args& k, const mi_camera_de
         float ms = 0.0f;
         if (hipEventElapsedTime(&ms, c->wf_ev[e], c->wf_ev[e + 1]) == hipSuccess) c->wf_ms[ev_kind[e] < 3 ? ev_kind[e] : ev_kind[e] + 1] += ms;
         if (c->tune.dump_launches) {
-            static const char* const names[5] = { "wf_main", "wf_trav", "wf_reduce", "wf_trav_f", "wf_replay" };
+            static const char* const names[6] = { "wf_main", "wf_trav", "wf_reduce", "wf_trav_f", "wf_replay", "wf_main (class A, beside the walkers)" };
             fprintf(stderr, "[mi_rt] launch %zu %s %.4f ms\n", e / 2, names[ev_kind[e]], ms);
         }
     }

@@ -225,6 +225,8 @@ struct WfArgs {
     uint32_t region;      // slots per shard region (multiple of 256)
     uint32_t n_in;        // iteration 0: number of new paths (npix * s_count)
     uint32_t n_blocks_in; // iteration > 0: blocks to run = sum over shards of ceil(count/256)
+    uint32_t part;        // a pass after the first may be launched in two parts: 0 = all blocks, 1 = the class-A blocks only, 2 = the class-B blocks
+                          // only.  The grid may be larger than the part (a host-side upper bound): surplus blocks return at once
     uint32_t iter0;       // 1 = generate camera rays (first iteration of a batch)
     uint32_t s_base;      // first sample index of this batch
     uint32_t s_count;     // samples per pixel in this batch

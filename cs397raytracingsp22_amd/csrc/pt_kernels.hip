@@ -1418,7 +1418,16 @@ __global__ __launch_bounds__(kBlock, PT_MAIN_WAVES) void wf_main(WfArgs A) {
     bvh_bind(B, S, 0);     // roots come from global memory (scalar load: wave-uniform address)
     const float t_min = 0.001f, t_max = C.max_trace_dist;
     const uint32_t cap = A.cap;
-    const uint32_t out_shard = blockIdx.x % (uint32_t)kWfShards;
+    // `bid` = the block's number within the whole pass.  A pass after the first may be launched in two parts (class-A blocks
+    // beside the walkers of the previous pass, class-B blocks behind them) and on a grid that is only an upper bound of the part
+    // (the host did not wait for the previous pass' header): the device-side block table says where the part really ends.
+    uint32_t bid = blockIdx.x;
+    if (!A.iter0) {
+        const uint32_t blocks_a = A.in_blkpfx[kWfShards], blocks_all = A.in_blkpfx[2 * kWfShards];
+        if (A.part == 2u) bid += blocks_a;
+        if (bid >= (A.part == 1u ? blocks_a : blocks_all)) return;
+    }
+    const uint32_t out_shard = bid % (uint32_t)kWfShards;
 
 #ifdef PT_WF_STAMPS
 #define WF_STAMP(k) do { __builtin_amdgcn_s_waitcnt(0); stamp[k] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -1434,13 +1443,13 @@ __global__ __launch_bounds__(kBlock, PT_MAIN_WAVES) void wf_main(WfArgs A) {
     // 1024 | npix, 256 | 1024, so both words are wave-uniform and stay in SGPRs)
     unsigned long long list_mask = ~0ull, mesh_word = 0xffffffffull;
     if (A.iter0 && A.tile_mask) {
-        const uint32_t slot0 = ((blockIdx.x * kBlock) % A.npix) / kTilePixels;
+        const uint32_t slot0 = ((bid * kBlock) % A.npix) / kTilePixels;
         const uint32_t tile0 = slot0 * (uint32_t)A.R.world + (uint32_t)A.R.rank;
         if (tile0 < A.R.tiles_total) { list_mask = A.tile_mask[tile0]; mesh_word = A.tile_mask[A.R.tiles_total + tile0]; }
     }
     if (A.iter0) {
         // ---- Camera::generate_rays (tracing.rs:159-209) ----
-        const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+        const uint32_t i = bid * kBlock + threadIdx.x;
         const bool valid = i < A.n_in;
         if (!SIG && (mesh_word >> 63)) {
             // nothing is reachable from this tile: every sample is the black background (tracing.rs:306).
@@ -1476,7 +1485,7 @@ __global__ __launch_bounds__(kBlock, PT_MAIN_WAVES) void wf_main(WfArgs A) {
         // loads can even be issued).  Only the starting point is approximate; the walk is exact.
         uint32_t lo;
         {
-            const uint32_t b = blockIdx.x;
+            const uint32_t b = bid;
             const uint32_t blocks_a = A.in_blkpfx[kWfShards], blocks_all = A.in_blkpfx[2 * kWfShards];
             const bool in_b = b >= blocks_a;
             const uint32_t base = in_b ? (uint32_t)kWfShards : 0u, first = in_b ? blocks_a : 0u;
@@ -1491,7 +1500,7 @@ __global__ __launch_bounds__(kBlock, PT_MAIN_WAVES) void wf_main(WfArgs A) {
         WF_STAMP(1);
         const bool cls_b = lo >= (uint32_t)kWfShards;
         const uint32_t in_shard = cls_b ? lo - (uint32_t)kWfShards : lo;
-        const uint32_t local = (blockIdx.x - A.in_blkpfx[lo]) * kBlock + threadIdx.x;
+        const uint32_t local = (bid - A.in_blkpfx[lo]) * kBlock + threadIdx.x;
         const bool valid = local < A.in_count[lo];
         alive = valid;
         const uint32_t lv = valid ? local : 0u;
@@ -1621,7 +1630,7 @@ __global__ __launch_bounds__(kBlock, PT_MAIN_WAVES) void wf_main(WfArgs A) {
     if (alive && enters) A.trav_q[(size_t)out_shard * A.region + qpos] = (uint32_t)pos;
 #ifdef PT_WF_STAMPS
     WF_STAMP(6);       // waits for the state stores too
-    if (A.diag && (blockIdx.x & 63u) == 0u && threadIdx.x == 0) {
+    if (A.diag && (bid & 63u) == 0u && threadIdx.x == 0) {
         unsigned long long* d = A.diag + (A.iter0 ? 8 : 0);
         for (int k = 0; k < 6; k++) if (stamp[k + 1] && stamp[k]) atomicAdd(&d[k], stamp[k + 1] - stamp[k]);
         atomicAdd(&d[6], 1ull);
@@ -2230,6 +2239,7 @@ __global__ __launch_bounds__(256) void wf_prefix(uint32_t* __restrict__ out_coun
         // the host's copy goes straight into pinned host memory (no copy kernel that would queue behind the
         // persistent walkers): data, system-scope fence, then the sequence number the host polls
         host_hdr[0] = blocks_a + x1; host_hdr[1] = x3; host_hdr[2] = x2; host_hdr[4] = tot_b;     // [4]: class-B paths (statistics only)
+        host_hdr[5] = blocks_a;                                                                    // [5]: the class-A blocks come first
         __threadfence_system();
         host_hdr[3] = seq;
     }

@@ -150,7 +150,7 @@ class Context:
         out = (C.c_float * 8)()
         abi.check(self._lib.mi_last_pipeline_ms(self._h, out))
         return {"wf_main_ms": float(out[0]), "wf_trav_ms": float(out[1]), "wf_reduce_ms": float(out[2]), "launches": int(out[3]),
-                "wf_trav_f_ms": float(out[4]), "wf_replay_ms": float(out[5])}
+                "wf_trav_f_ms": float(out[4]), "wf_replay_ms": float(out[5]), "wf_main_a_ms": float(out[6])}
 
     def last_pipeline_counts(self):
         """Path counts of the last wavefront render (mi_last_pipeline_counts), for traffic accounting."""

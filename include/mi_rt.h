@@ -274,7 +274,10 @@ int  mi_reserve(mi_ctx* ctx, const mi_camera_desc* cam, int32_t world, uint64_t 
 
 /* Wavefront pipeline (MI_VARIANT_WAVEFRONT) of the most recent render: out8 = { sum of wf_main
  * launch durations, of wf_trav, of wf_reduce (ms, HIP events around every launch), launches, sum of wf_trav_f, of
- * wf_replay (the two-stage mesh traversal), 0, 0 }. */
+ * wf_replay (the two-stage mesh traversal), sum of the spans of wf_main's class-A parts, 0 }.  A pass after the first launches
+ * wf_main in two parts: the class-A blocks run on a second stream BESIDE the walkers of the previous pass (their span includes
+ * waiting for CUs the walkers still hold, so it overlaps the wf_trav figure and must not be added to it), the class-B blocks
+ * behind the walkers (counted under wf_main). */
 int  mi_last_pipeline_ms(mi_ctx* ctx, float* out8);
 
 /* Path counts of the most recent wavefront render, for traffic accounting: out8 = { passes (wf_main launches
