@@ -15,12 +15,12 @@ LIB_PATH = os.path.join(_HERE, "lib", "libmi_rt.so")
 MI_TILE = 32
 
 # status codes (mi_status)
-MI_RT_ABI_VERSION = 3      # include/mi_rt.h
+MI_RT_ABI_VERSION = 4      # include/mi_rt.h
 MI_OK, MI_ERR_INVALID, MI_ERR_UNSUPPORTED, MI_ERR_NO_DEVICE, MI_ERR_HIP, MI_ERR_OOM, MI_ERR_NO_SCENE = 0, -1, -2, -3, -4, -5, -6
 # material kinds
 MI_MAT_LAMBERTIAN, MI_MAT_METAL, MI_MAT_DIELECTRIC, MI_MAT_PARAMETERIZED, MI_MAT_ISOTROPIC = range(5)
 # object kinds
-MI_OBJ_SPHERE, MI_OBJ_TRIANGLE, MI_OBJ_PLANE, MI_OBJ_VOLUME, MI_OBJ_MESH = range(5)
+MI_OBJ_SPHERE, MI_OBJ_TRIANGLE, MI_OBJ_PLANE, MI_OBJ_VOLUME, MI_OBJ_MESH, MI_OBJ_SCENE = range(6)
 MI_PROJ_ORTHOGRAPHIC, MI_PROJ_PERSPECTIVE = 0, 1
 MI_SHADE_PHONG, MI_SHADE_PATHTRACE = 0, 1
 MI_VARIANT_DEFAULT, MI_VARIANT_SIMPLE, MI_VARIANT_VOTED, MI_VARIANT_VOTED_DIAG = 0, 1, 3, 4      # 2, 5, 6: removed in ABI 3
@@ -55,7 +55,8 @@ class mi_plane(C.Structure):
 
 class mi_volume(C.Structure):
     _fields_ = [("boundary_center", f3), ("boundary_radius", C.c_float), ("density", C.c_float),
-                ("phase_material", C.c_int32)]
+                ("phase_material", C.c_int32), ("boundary_kind", C.c_int32), ("boundary_index", C.c_int32),
+                ("boundary_count", C.c_int32)]
 
 
 class mi_texture(C.Structure):
@@ -79,6 +80,7 @@ class mi_scene_desc(C.Structure):
                 ("meshes", C.POINTER(mi_mesh)), ("n_meshes", C.c_int32),
                 ("materials", C.POINTER(mi_material)), ("n_materials", C.c_int32),
                 ("textures", C.POINTER(mi_texture)), ("n_textures", C.c_int32),
+                ("boundary_objects", C.POINTER(mi_object)), ("n_boundary_objects", C.c_int32),
                 ("point_light_pos", f3), ("ambient", f3)]
 
 

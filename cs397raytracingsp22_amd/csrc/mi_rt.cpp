@@ -34,9 +34,9 @@
 
 namespace pt {
 hipError_t launch_megakernel(const K1Args& args, uint32_t n_blocks, bool lds, bool sig, size_t lds_bytes, hipStream_t stream);
-hipError_t launch_megakernel_voted(const K1Args& args, uint32_t n_blocks, bool lds, bool sig, bool diag,
+hipError_t launch_megakernel_voted(const K1Args& args, uint32_t n_blocks, bool lds, bool sig, bool diag, bool gv,
                                    size_t lds_bytes, hipStream_t stream);
-hipError_t launch_wf_main(const WfArgs& a, uint32_t n_blocks, bool sig, hipStream_t stream);
+hipError_t launch_wf_main(const WfArgs& a, uint32_t n_blocks, bool sig, bool gv, hipStream_t stream);
 hipError_t launch_phong(const K1Args& a, uint32_t n_blocks, bool sig, hipStream_t stream);
 hipError_t launch_branch(const K1Args& a, uint32_t n_blocks, uint32_t path_samples, bool sig, hipStream_t stream);
 hipError_t launch_wf_trav(const WfArgs& a, uint32_t n_blocks, int lds_mode, size_t lds_bytes, bool* big_lds_enabled, hipStream_t stream);
@@ -98,6 +98,7 @@ struct mi_ctx {
     void* blob = nullptr; size_t blob_bytes = 0;
     DScene S{};
     bool have_scene = false;
+    bool gen_volumes = false;                // a ConvexVolume whose boundary is not the inline sphere: the kernels' GV forms
     uint32_t lds_bytes = 0;                  // bytes needed to stage nodes + tris, 0 = no meshes
     // per live mesh (Scene.objects order): end of its nodes in the node pool, does the two-stage bound apply to it at all,
     // is it walked two-stage by default (qualifies and large enough for the F-tree to pay)
@@ -407,10 +408,44 @@ extern "C" int mi_scene_upload(mi_ctx* c, const mi_scene_desc* d) {
     }
     // Pool placement: meshes walked through the reference's tree first, so that one LDS window over the head of the node
     // pool covers exactly the trees wf_trav needs.  (The order of Scene.objects — ties, RNG draws — is not touched.)
+    // Who references which mesh: Scene.objects entries, and ConvexVolume boundaries (a StaticMesh, or a nested Scene's entries).
+    // Trees nobody references are not placed at all; boundary-only trees go last (they are walked from global memory).
+    std::vector<uint8_t> obj_ref((size_t)d->n_meshes, 0), bnd_ref((size_t)d->n_meshes, 0);
+    if (d->n_boundary_objects < 0 || (d->n_boundary_objects > 0 && !d->boundary_objects)) return fail(MI_ERR_INVALID, "bad boundary_objects");
+    for (int i = 0; i < d->n_objects; i++)
+        if (d->objects[i].kind == MI_OBJ_MESH) {
+            if (d->objects[i].index < 0 || d->objects[i].index >= d->n_meshes) return fail(MI_ERR_INVALID, "object %d: bad mesh index", i);
+            obj_ref[(size_t)d->objects[i].index] = 1;
+        }
+    for (int v = 0; v < d->n_volumes && d->volumes; v++) {
+        const mi_volume& vo = d->volumes[v];
+        auto mark = [&](int kind, int index) -> int {
+            if (kind == MI_OBJ_MESH) {
+                if (index < 0 || index >= d->n_meshes) return fail(MI_ERR_INVALID, "volume %d: bad boundary mesh index", v);
+                bnd_ref[(size_t)index] = 1;
+            }
+            return MI_OK;
+        };
+        if (vo.boundary_kind == MI_OBJ_SCENE) {
+            if (vo.boundary_index < 0 || vo.boundary_count < 0 || (int64_t)vo.boundary_index + vo.boundary_count > d->n_boundary_objects)
+                return fail(MI_ERR_INVALID, "volume %d: boundary entries out of range", v);
+            for (int k = 0; k < vo.boundary_count; k++) {
+                const mi_object& e = d->boundary_objects[vo.boundary_index + k];
+                const int rcm = mark(e.kind, e.index);
+                if (rcm != MI_OK) return rcm;
+            }
+        } else {
+            const int rcm = mark(vo.boundary_kind, vo.boundary_index);
+            if (rcm != MI_OK) return rcm;
+        }
+    }
     {
         std::vector<int> order;
-        for (int pass = 0; pass < 2; pass++)
-            for (int mi = 0; mi < d->n_meshes; mi++) if ((mb[(size_t)mi].default_ts ? 1 : 0) == pass) order.push_back(mi);
+        for (int pass = 0; pass < 3; pass++)
+            for (int mi = 0; mi < d->n_meshes; mi++) {
+                const int cls = obj_ref[(size_t)mi] ? (mb[(size_t)mi].default_ts ? 1 : 0) : (bnd_ref[(size_t)mi] ? 2 : 3);
+                if (cls == pass) order.push_back(mi);
+            }
         for (int mi : order) {
             MeshBuild& B = mb[(size_t)mi];
             DMesh& M = meshes[(size_t)mi];
@@ -443,27 +478,22 @@ extern "C" int mi_scene_upload(mi_ctx* c, const mi_scene_desc* d) {
         }
     }
 
-    // Scene.objects in order
-    for (int i = 0; i < d->n_objects; i++) {
-        const mi_object& o = d->objects[i];
-        DObject& D = objs[(size_t)i];
-        memset(&D, 0, sizeof D);
-        D.kind = o.kind;
-        D.index = i;
-        switch (o.kind) {
+    // one Sphere / Triangle / Plane record (Scene.objects entry or boundary entry), derived constants hoisted
+    auto fill_primitive = [&](int kind, int index, const char* what, int i, DObject& D) -> int {
+        switch (kind) {
         case MI_OBJ_SPHERE: {
-            if (o.index < 0 || o.index >= d->n_spheres || !d->spheres) return fail(MI_ERR_INVALID, "object %d: bad sphere index", i);
-            const mi_sphere& s = d->spheres[o.index];
-            if (!mat_ok(s.material)) return fail(MI_ERR_INVALID, "object %d: bad material", i);
+            if (index < 0 || index >= d->n_spheres || !d->spheres) return fail(MI_ERR_INVALID, "%s %d: bad sphere index", what, i);
+            const mi_sphere& s = d->spheres[index];
+            if (!mat_ok(s.material)) return fail(MI_ERR_INVALID, "%s %d: bad material", what, i);
             D.material = s.material;
             D.f[0] = s.center[0]; D.f[1] = s.center[1]; D.f[2] = s.center[2]; D.f[3] = s.radius;
             D.f[4] = s.radius * s.radius;                               // geometry.rs:400
-            break;
+            return MI_OK;
         }
         case MI_OBJ_TRIANGLE: {
-            if (o.index < 0 || o.index >= d->n_triangles || !d->triangles) return fail(MI_ERR_INVALID, "object %d: bad triangle index", i);
-            const mi_triangle& t = d->triangles[o.index];
-            if (!mat_ok(t.material)) return fail(MI_ERR_INVALID, "object %d: bad material", i);
+            if (index < 0 || index >= d->n_triangles || !d->triangles) return fail(MI_ERR_INVALID, "%s %d: bad triangle index", what, i);
+            const mi_triangle& t = d->triangles[index];
+            if (!mat_ok(t.material)) return fail(MI_ERR_INVALID, "%s %d: bad material", what, i);
             D.material = t.material;
             h3 a = H3p(t.a), e1 = sub(H3p(t.b), a), e2 = sub(H3p(t.c), a);      // geometry.rs:434-435
             h3 n = normalize(cross(e1, e2));                                    // geometry.rs:449
@@ -471,14 +501,36 @@ extern "C" int mi_scene_upload(mi_ctx* c, const mi_scene_desc* d) {
             D.f[3] = e1.x; D.f[4] = e1.y; D.f[5] = e1.z;
             D.f[6] = e2.x; D.f[7] = e2.y; D.f[8] = e2.z;
             D.f[9] = n.x; D.f[10] = n.y; D.f[11] = n.z;
-            break;
+            return MI_OK;
         }
         case MI_OBJ_PLANE: {
-            if (o.index < 0 || o.index >= d->n_planes || !d->planes) return fail(MI_ERR_INVALID, "object %d: bad plane index", i);
-            const mi_plane& p = d->planes[o.index];
-            if (!mat_ok(p.material)) return fail(MI_ERR_INVALID, "object %d: bad material", i);
+            if (index < 0 || index >= d->n_planes || !d->planes) return fail(MI_ERR_INVALID, "%s %d: bad plane index", what, i);
+            const mi_plane& p = d->planes[index];
+            if (!mat_ok(p.material)) return fail(MI_ERR_INVALID, "%s %d: bad material", what, i);
             D.material = p.material;
             for (int k = 0; k < 3; k++) { D.f[k] = p.point[k]; D.f[3 + k] = p.normal[k]; }
+            return MI_OK;
+        }
+        default: return fail(MI_ERR_INVALID, "%s %d: unknown kind %d", what, i, kind);
+        }
+    };
+    // boundary records of the ConvexVolumes that are not plain spheres; boundary meshes get entries of the device's mesh table
+    // BEHIND the Scene.objects meshes (bmesh_of: mesh index -> entry, filled below once the live table exists)
+    std::vector<DObject> bobjs;
+    std::vector<std::pair<size_t, int>> bmesh_fix;        // (record in bobjs, mi_mesh index) to be pointed at its table entry
+
+    // Scene.objects in order
+    for (int i = 0; i < d->n_objects; i++) {
+        const mi_object& o = d->objects[i];
+        DObject& D = objs[(size_t)i];
+        memset(&D, 0, sizeof D);
+        D.kind = o.kind;
+        D.index = i;
+        D.ref = -1;
+        switch (o.kind) {
+        case MI_OBJ_SPHERE: case MI_OBJ_TRIANGLE: case MI_OBJ_PLANE: {
+            const int rcp = fill_primitive(o.kind, o.index, "object", i, D);
+            if (rcp != MI_OK) return rcp;
             break;
         }
         case MI_OBJ_VOLUME: {
@@ -486,24 +538,41 @@ extern "C" int mi_scene_upload(mi_ctx* c, const mi_scene_desc* d) {
             const mi_volume& v = d->volumes[o.index];
             if (!mat_ok(v.phase_material)) return fail(MI_ERR_INVALID, "object %d: bad phase material", i);
             D.material = v.phase_material;
-            for (int k = 0; k < 3; k++) D.f[k] = v.boundary_center[k];
-            D.f[3] = v.boundary_radius;
-            D.f[4] = v.boundary_radius * v.boundary_radius;             // geometry.rs:400 via :505
             D.f[5] = -1.0f / v.density;                                 // geometry.rs:517
+            if (v.boundary_kind == MI_OBJ_SPHERE) {                     // the inline sphere: what every use in the reference is
+                for (int k = 0; k < 3; k++) D.f[k] = v.boundary_center[k];
+                D.f[3] = v.boundary_radius;
+                D.f[4] = v.boundary_radius * v.boundary_radius;         // geometry.rs:400 via :505
+                break;
+            }
+            // any other `Arc<dyn Intersectable>` (geometry.rs:496): its records, tested twice per ray by the kernels (:505,508)
+            std::vector<mi_object> entries;
+            if (v.boundary_kind == MI_OBJ_SCENE) for (int k = 0; k < v.boundary_count; k++) entries.push_back(d->boundary_objects[v.boundary_index + k]);
+            else { mi_object e; e.kind = v.boundary_kind; e.index = v.boundary_index; entries.push_back(e); }
+            D.ref = (int)bobjs.size();
+            { const int n = (int)entries.size(); memcpy(&D.f[6], &n, 4); }
+            for (size_t k = 0; k < entries.size(); k++) {
+                DObject R; memset(&R, 0, sizeof R);
+                R.kind = entries[k].kind; R.index = (int)k; R.ref = -1;
+                if (entries[k].kind == MI_OBJ_MESH) { R.material = -1; bmesh_fix.emplace_back(bobjs.size(), entries[k].index); }
+                else if (entries[k].kind == MI_OBJ_VOLUME || entries[k].kind == MI_OBJ_SCENE)
+                    return fail(MI_ERR_UNSUPPORTED, "object %d: a ConvexVolume or a Scene inside a ConvexVolume boundary", i);
+                else { const int rcp = fill_primitive(entries[k].kind, entries[k].index, "boundary entry of object", i, R); if (rcp != MI_OK) return rcp; }
+                bobjs.push_back(R);
+            }
             break;
         }
         case MI_OBJ_MESH: {
-            if (o.index < 0 || o.index >= d->n_meshes) return fail(MI_ERR_INVALID, "object %d: bad mesh index", i);
-            if (meshes[(size_t)o.index].object_index >= 0)
-                return fail(MI_ERR_UNSUPPORTED, "object %d: a StaticMesh may appear once in Scene.objects", i);
-            meshes[(size_t)o.index].object_index = i;
+            // the same StaticMesh may appear several times (Arc sharing, tracing.rs:215): every appearance is an entry of its own
+            // in the device's mesh table — sharing the nodes, triangles and attributes in the pools — with its own object index
             D.ref = o.index; D.material = -1;
             break;
         }
         default: return fail(MI_ERR_INVALID, "object %d: unknown kind %d", i, o.kind);
         }
     }
-    // meshes that are not referenced by Scene.objects are not part of the scene
+    // The device's mesh table: one entry per MESH entry of Scene.objects, in that order (S.n_meshes of them: what the hit loop
+    // walks), then one per boundary mesh (reached only through a ConvexVolume's boundary record).
     std::vector<DMesh> live;
     std::vector<DMeshF> livef;
     c->mesh_node_end.clear(); c->mesh_e2_end.clear(); c->mesh_qualifies.clear(); c->mesh_default_ts.clear();
@@ -511,10 +580,17 @@ extern "C" int mi_scene_upload(mi_ctx* c, const mi_scene_desc* d) {
         if (objs[(size_t)i].kind == OBJ_MESH) {
             int r = objs[(size_t)i].ref; objs[(size_t)i].ref = (int)live.size();
             live.push_back(meshes[(size_t)r]); livef.push_back(meshf[(size_t)r]);
+            live.back().object_index = i;
             c->mesh_node_end.push_back(meshes[(size_t)r].node_end);
             c->mesh_e2_end.push_back(meshes[(size_t)r].e2_begin + meshes[(size_t)r].n_tris);
             c->mesh_qualifies.push_back(mb[(size_t)r].qualifies ? 1 : 0); c->mesh_default_ts.push_back(mb[(size_t)r].default_ts ? 1 : 0);
         }
+    const size_t n_scene_meshes = live.size();
+    for (auto& fx : bmesh_fix) {
+        bobjs[fx.first].ref = (int)live.size();
+        live.push_back(meshes[(size_t)fx.second]); livef.push_back(meshf[(size_t)fx.second]);
+        live.back().object_index = -1;
+    }
 
     // kind-grouped copy of the non-mesh objects (stable within a kind)
     std::vector<DObject> list;
@@ -528,8 +604,8 @@ extern "C" int mi_scene_upload(mi_ctx* c, const mi_scene_desc* d) {
     // world-space corners of the root boxes (tile masks).  The rays reach object space through inv_transform
     // (geometry.rs:304), so the corners come from ITS inverse (f64), not from `transform`; a projective
     // inv_transform or a single-triangle mesh (no root box) is never culled.
-    c->h_mesh_box.assign(live.size(), mi_ctx::MeshBox{ false, {} });
-    for (size_t m = 0; m < live.size(); m++) {
+    c->h_mesh_box.assign(n_scene_meshes, mi_ctx::MeshBox{ false, {} });
+    for (size_t m = 0; m < n_scene_meshes; m++) {
         const DMesh& M = live[m];
         const float* it = M.inv_transform;
         if (!(it[3] == 0.0f && it[7] == 0.0f && it[11] == 0.0f && it[15] == 1.0f)) continue;
@@ -563,7 +639,8 @@ extern "C" int mi_scene_upload(mi_ctx* c, const mi_scene_desc* d) {
     auto align = [](size_t x) { return (x + 255) & ~(size_t)255; };
     size_t off_obj = 0;
     size_t off_list = align(off_obj + objs.size() * sizeof(DObject));
-    size_t off_mat = align(off_list + (list.size() + 1) * sizeof(DObject));      // +1: the loop prefetches one record ahead
+    size_t off_bobj = align(off_list + (list.size() + 1) * sizeof(DObject));     // +1: the loop prefetches one record ahead
+    size_t off_mat = align(off_bobj + (bobjs.size() + 1) * sizeof(DObject));
     size_t off_mesh = align(off_mat + mats.size() * sizeof(DMaterial));
     size_t off_meshf = align(off_mesh + live.size() * sizeof(DMesh));
     size_t off_fnodes = align(off_meshf + livef.size() * sizeof(DMeshF));
@@ -580,6 +657,7 @@ extern "C" int mi_scene_upload(mi_ctx* c, const mi_scene_desc* d) {
     auto put = [&](size_t off, const void* p, size_t n) { if (n) memcpy(host.data() + off, p, n); };
     put(off_obj, objs.data(), objs.size() * sizeof(DObject));
     put(off_list, list.data(), list.size() * sizeof(DObject));
+    put(off_bobj, bobjs.data(), bobjs.size() * sizeof(DObject));
     put(off_mat, mats.data(), mats.size() * sizeof(DMaterial));
     put(off_mesh, live.data(), live.size() * sizeof(DMesh));
     put(off_meshf, livef.data(), livef.size() * sizeof(DMeshF));
@@ -600,6 +678,8 @@ extern "C" int mi_scene_upload(mi_ctx* c, const mi_scene_desc* d) {
     uint8_t* b = (uint8_t*)c->blob;
     c->S.objects = (const DObject*)(b + off_obj);
     c->S.list = (const DObject*)(b + off_list);
+    c->S.bobjs = (const DObject*)(b + off_bobj);
+    c->gen_volumes = !bobjs.empty();
     c->h_list = list; c->h_n_tri = n_list[0]; c->h_n_sphere = n_list[1]; c->h_n_unmasked = n_list[2] + n_list[3]; c->mask_valid = false;
     c->S.n_list_tri = n_list[0]; c->S.n_list_sphere = n_list[1]; c->S.n_list_plane = n_list[2]; c->S.n_list_volume = n_list[3];
     c->S.materials = (const DMaterial*)(b + off_mat);
@@ -615,7 +695,7 @@ extern "C" int mi_scene_upload(mi_ctx* c, const mi_scene_desc* d) {
     c->S.textures = (const DTexture*)(b + off_tex);
     c->S.texels = (const uint8_t*)(b + off_texel);
     c->S.n_objects = (int)objs.size();
-    c->S.n_meshes = (int)live.size();
+    c->S.n_meshes = (int)n_scene_meshes;
     c->S.n_nodes = (int)(nodes.size() / 8);
     c->S.n_tris = (int)(tris.size() / 12);
     c->lds_bytes = (uint32_t)((nodes.size() + tris.size()) * 4);
@@ -1119,14 +1199,14 @@ static int render_tiles_wavefront(mi_ctx* c, const K1Args& k, const mi_camera_de
             if (split) {
                 HIP_TRY(hipStreamWaitEvent(c->aux_stream, c->ev_pfx, 0));
                 a.part = 1;
-                WF_TIMED_ON(5, c->aux_stream, launch_wf_main(a, grid_a, d_sig != nullptr, c->aux_stream));     // kind 5: its span includes waiting for CUs
+                WF_TIMED_ON(5, c->aux_stream, launch_wf_main(a, grid_a, d_sig != nullptr, c->gen_volumes, c->aux_stream));     // kind 5: its span includes waiting for CUs
                 HIP_TRY(hipEventRecord(c->ev_part, c->aux_stream));
                 a.part = 2;
-                WF_TIMED(0, launch_wf_main(a, exact ? grid_all - grid_a : grid_all, d_sig != nullptr, stream));
+                WF_TIMED(0, launch_wf_main(a, exact ? grid_all - grid_a : grid_all, d_sig != nullptr, c->gen_volumes, stream));
                 HIP_TRY(hipStreamWaitEvent(stream, c->ev_part, 0));
             } else {
                 a.part = 0;
-                WF_TIMED(0, launch_wf_main(a, grid_all, d_sig != nullptr, stream));
+                WF_TIMED(0, launch_wf_main(a, grid_all, d_sig != nullptr, c->gen_volumes, stream));
             }
             // device-side bookkeeping: tables for the next pass and for wf_trav, and the header the host needs (grid of the
             // next pass, anything alive?), which wf_prefix stores straight into pinned host memory: the compute stream never
@@ -1234,7 +1314,7 @@ static int render_tiles(mi_ctx* c, const mi_camera_desc* cam, const mi_render_op
         int rcw = render_tiles_wavefront(c, a, cam, wa, wf_batch, lds, o->flags, d_compact, a.sig, range, stream);
         if (rcw != MI_OK) return rcw;
     } else if (variant == MI_VARIANT_VOTED || variant == MI_VARIANT_VOTED_DIAG)
-        HIP_TRY(launch_megakernel_voted(a, n_blocks, lds, a.sig != nullptr, diag, c->lds_bytes + c->tune.lds_pad, stream));
+        HIP_TRY(launch_megakernel_voted(a, n_blocks, lds, a.sig != nullptr, diag, c->gen_volumes, c->lds_bytes + c->tune.lds_pad, stream));
     else
         HIP_TRY(launch_megakernel(a, n_blocks, lds, a.sig != nullptr, c->lds_bytes, stream));
     HIP_TRY(hipEventRecord(c->ev_stop, stream));

@@ -41,7 +41,8 @@ enum : int { MAT_LAMBERTIAN = 0, MAT_METAL = 1, MAT_DIELECTRIC = 2, MAT_PARAMETE
 //   SPHERE   f[0..2] center, f[3] radius, f[4] radius*radius
 //   TRIANGLE f[0..2] a, f[3..5] e1=b-a, f[6..8] e2=c-a, f[9..11] normalize(e1 x e2)
 //   PLANE    f[0..2] point, f[3..5] normal
-//   VOLUME   f[0..2] boundary center, f[3] radius, f[4] radius*radius, f[5] -1/density
+//   VOLUME   f[0..2] boundary center, f[3] radius, f[4] radius*radius, f[5] -1/density; ref = -1: that inline sphere is the boundary,
+//            else ref = first of int(f[6]) boundary records in DScene.bobjs (a Triangle / Plane / StaticMesh, or a nested Scene's entries)
 //   MESH     ref = mesh index
 // Every derived value is computed on the host with the same f32 operation the
 // reference performs per ray (geometry.rs:400,434-435,449,517), so hoisting it is exact.
@@ -137,6 +138,9 @@ struct DScene {
     // independent, ties go to the lower Scene.objects index (tracing.rs:335), and only
     // volumes draw random numbers, in their original relative order (geometry.rs:517).
     const PT_CONST_AS DObject*   list;
+    // boundary records of ConvexVolumes whose boundary is not the inline sphere (same record format; MESH: ref = entry of `meshes`
+    // at or behind n_meshes — the table holds the Scene.objects meshes first, then the boundary-only ones)
+    const PT_CONST_AS DObject*   bobjs;
     // two-stage traversal (meshes that qualify): F-tree nodes (same 2 x float4 node format; leaf word = (first << 3) | (count - 1)
     // into ftris), the F-ordered triangles {a.xyz, tri index}{e1.xyz, 0}{e2.xyz, 0}, and the per-mesh constants
     const PT_CONST_AS float*     fnodes;

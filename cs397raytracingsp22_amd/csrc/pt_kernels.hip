@@ -584,9 +584,60 @@ __device__ __forceinline__ void resolve_hit(const DScene& S, const Best& b, f3 o
     }
 }
 
-// One non-mesh object of Scene.objects against the ray (wave-uniform `ob`).
+// Plane::intersect_ray geometry.rs:474-489 -> parametric t, or miss
 template <class OP>
-__device__ __forceinline__ void test_object(OP ob, int idx, f3 o, f3 d, float t_min, float t_max,
+__device__ __forceinline__ bool plane_t(OP ob, f3 o, f3 d, float t_min, float t_max, float& t_out) {
+    f3 normal = ld3(ob->f + 3);
+    float origin_dist = dot(o - ld3(ob->f), normal);
+    float sg = (origin_dist != origin_dist) ? origin_dist : (__float_as_uint(origin_dist) >> 31 ? -1.0f : 1.0f);
+    f3 n = normal * sg;
+    float dd = dot(d, n);
+    float t = fabsf(origin_dist) / fabsf(dd);
+    t_out = t;
+    return !(dd >= 0.0f) && !(t < t_min || t > t_max);
+}
+
+// `self.boundary.intersect_ray(ray, t_min, t_max)` of a ConvexVolume (geometry.rs:505,508) -> distance of the boundary's hit.
+// The boundary is the inline sphere (ref < 0: every use in the reference), or the records S.bobjs[ref ..): one Triangle / Plane /
+// StaticMesh, or the entries of a nested Scene, whose answer is its closest hit — strictly closer wins, the first entry keeps a
+// tie (tracing.rs:333-336).  A StaticMesh boundary is walked in line from global memory (geometry.rs:301-314, object-space ray,
+// parametric t): a rare kind, not a tuned path.  No random number is drawn in here.
+// GV = false compiles the sphere only: the hot kernels exist in both forms and the host launches the GV form only for a scene
+// that holds such a boundary (the generic code costs wf_main 2 VGPRs, 30 scalar spills and 5 % on cfg5 even when it never runs).
+template <bool GV, class OP>
+__device__ __forceinline__ bool boundary_hit(const DScene& S, OP ob, f3 o, f3 d, float t_min, float t_max, float& t_out) {
+    if (!GV || ob->ref < 0) return sphere_t(o, d, ld3(ob->f), ob->f[4], t_min, t_max, t_out);
+    const int first = ob->ref, n = __float_as_int(ob->f[6]);
+    bool have = false;
+    float best = 0.0f;
+    for (int k = 0; k < n; k++) {
+        auto r = &S.bobjs[first + k];
+        const int kind = r->kind;
+        float t = 0.0f;
+        bool ok;
+        if (kind == OBJ_TRIANGLE) { float u, v; ok = tri_t(o, d, ld3(r->f), ld3(r->f + 3), ld3(r->f + 6), t_min, t_max, t, u, v); }
+        else if (kind == OBJ_SPHERE) ok = sphere_t(o, d, ld3(r->f), r->f[4], t_min, t_max, t);
+        else if (kind == OBJ_PLANE) ok = plane_t(r, o, d, t_min, t_max, t);
+        else {                                                            // OBJ_MESH
+            Bvh<false> G;
+            bvh_bind(G, S, 0);
+            auto M = &S.meshes[r->ref];
+            const f3 oo = xform_point(M->inv_transform, o), od = xform_vector(M->inv_transform, d);
+            float bu, bv; int btri;
+            traverse_mesh(G, M->node_begin, M->node_end, M->tri_begin, oo, od, t_min, t_max, t, btri, bu, bv);
+            ok = btri >= 0;
+        }
+        const bool take = ok && (!have || t < best);
+        best = take ? t : best;
+        have = have || take;
+    }
+    t_out = best;
+    return have;
+}
+
+// One non-mesh object of Scene.objects against the ray (wave-uniform `ob`).
+template <bool GV = true, class OP>
+__device__ __forceinline__ void test_object(const DScene& S, OP ob, int idx, f3 o, f3 d, float t_min, float t_max,
                                             Rng& rng, Best& best) {
     int kind = ob->kind;
     if (kind == OBJ_TRIANGLE) {
@@ -597,22 +648,13 @@ __device__ __forceinline__ void test_object(OP ob, int idx, f3 o, f3 d, float t_
         float t;
         if (sphere_t(o, d, ld3(ob->f), ob->f[4], t_min, t_max, t)) consider(best, t, idx, -1, 0.0f, 0.0f);
     } else if (kind == OBJ_PLANE) {                                       // geometry.rs:474-489
-        f3 normal = ld3(ob->f + 3);
-        float origin_dist = dot(o - ld3(ob->f), normal);
-        float sg = (origin_dist != origin_dist) ? origin_dist : (__float_as_uint(origin_dist) >> 31 ? -1.0f : 1.0f);
-        f3 n = normal * sg;
-        float dd = dot(d, n);
-        if (!(dd >= 0.0f)) {
-            float t = fabsf(origin_dist) / fabsf(dd);
-            if (!(t < t_min || t > t_max)) consider(best, t, idx, -1, 0.0f, 0.0f);       // Plane: same class as Triangle
-        }
+        float t;
+        if (plane_t(ob, o, d, t_min, t_max, t)) consider(best, t, idx, -1, 0.0f, 0.0f);       // Plane: same class as Triangle
     } else if (kind == OBJ_VOLUME) {                                      // geometry.rs:502-526
         const float F32_MIN = -3.40282347e+38f, F32_MAX = 3.40282347e+38f;
-        f3 c = ld3(ob->f);
-        float r2 = ob->f[4];
         float t_entr, t_exit;
-        if (sphere_t(o, d, c, r2, F32_MIN, F32_MAX, t_entr) &&
-            sphere_t(o, d, c, r2, t_entr + 0.0001f, F32_MAX, t_exit)) {
+        if (boundary_hit<GV>(S, ob, o, d, F32_MIN, F32_MAX, t_entr) &&
+            boundary_hit<GV>(S, ob, o, d, t_entr + 0.0001f, F32_MAX, t_exit)) {
             if (!(t_exit < t_min || t_entr > t_max)) {
                 float t_start = fmaxf(t_entr, t_min);
                 float t_end = fminf(t_exit, t_max);
@@ -640,6 +682,7 @@ __device__ __forceinline__ void consider_list(Best& b, bool& have, bool ok, floa
     b.obj = take ? obj : b.obj;
     b.tri = take ? tag : b.tri;
 }
+template <bool GV = true>
 __device__ __forceinline__ void intersect_list(const DScene& S, f3 o, f3 d, float t_min, float t_max, Rng& rng, Best& best) {
     auto L = S.list;
     int k = 0;
@@ -676,7 +719,7 @@ __device__ __forceinline__ void intersect_list(const DScene& S, f3 o, f3 d, floa
         const int end = k + S.n_list_plane + S.n_list_volume;
         for (; k < end; k++) {
             auto ob = &L[k];
-            test_object(ob, ob->index, o, d, t_min, t_max, rng, best);
+            test_object<GV>(S, ob, ob->index, o, d, t_min, t_max, rng, best);
         }
     }
 }
@@ -685,6 +728,7 @@ __device__ __forceinline__ void intersect_list(const DScene& S, f3 o, f3 d, floa
 // ray of that tile (host-side conservative frustum test, mi_rt.cpp tile_masks), so skipping them
 // skips tests that would have missed.  `mask` is wave-uniform (SGPRs); planes and volumes are never
 // masked (a volume draws its random number for the whole ray LINE, geometry.rs:505).
+template <bool GV = true>
 __device__ __forceinline__ void intersect_list_masked(const DScene& S, unsigned long long mask, f3 o, f3 d,
                                                       float t_min, float t_max, Rng& rng, Best& best) {
     auto L = S.list;
@@ -708,7 +752,7 @@ __device__ __forceinline__ void intersect_list_masked(const DScene& S, unsigned 
     const int end = n_ts + S.n_list_plane + S.n_list_volume;
     for (int k = n_ts; k < end; k++) {
         auto ob = &L[k];
-        test_object(ob, ob->index, o, d, t_min, t_max, rng, best);
+        test_object<GV>(S, ob, ob->index, o, d, t_min, t_max, rng, best);
     }
 }
 
@@ -861,7 +905,7 @@ __global__ __launch_bounds__(kBlock) void pt_megakernel(K1Args A) {
         best.obj = -1; best.t = 0.0f; best.tri = -1; best.u = best.v = 0.0f;
         for (int k = 0; k < S.n_objects; k++) {
             auto ob = &S.objects[k];
-            if (ob->kind != OBJ_MESH) test_object(ob, k, P.o, P.d, t_min, t_max, P.rng, best);
+            if (ob->kind != OBJ_MESH) test_object(S, ob, k, P.o, P.d, t_min, t_max, P.rng, best);
         }
         for (int m = 0; m < S.n_meshes; m++) {                            // StaticMesh::intersect_ray geometry.rs:301-314
             auto M = &S.meshes[m];
@@ -1153,7 +1197,7 @@ __device__ __forceinline__ bool enter_next_mesh(const DScene& S, const BVH& B, i
     return false;
 }
 
-template <bool LDS, bool SIG, bool DIAG>
+template <bool LDS, bool SIG, bool DIAG, bool GV>
 __global__ __launch_bounds__(kBlock, PT_MIN_WAVES) void pt_megakernel_voted(K1Args A) {
     const DScene& S = A.S;
     const DCamera& C = A.C;
@@ -1269,7 +1313,7 @@ __global__ __launch_bounds__(kBlock, PT_MIN_WAVES) void pt_megakernel_voted(K1Ar
                 if (DIAG) { unsigned long long t = __builtin_amdgcn_s_memtime(); dg_cycGen += t - dg_t1; dg_t1 = t; }
                 if (state == ST_A && !fresh) {
                     best.obj = -1; best.t = 0.0f; best.tri = -1; best.u = best.v = 0.0f;
-                    intersect_list(S, P.o, P.d, t_min, t_max, P.rng, best);
+                    intersect_list<GV>(S, P.o, P.d, t_min, t_max, P.rng, best);
                     if (DIAG) did_list = true;
                     tm = 0;
                     if (enter_next_mesh(S, B, tm, P.o, P.d, t_min, t_max, too, tod, tinv, ti, tend, ttb)) {
@@ -1410,7 +1454,7 @@ __device__ __forceinline__ void wf_pixel_of(const WfArgs& A, uint32_t pix, uint3
     }
 }
 
-template <bool LDS, bool SIG>
+template <bool LDS, bool SIG, bool GV>
 __global__ __launch_bounds__(kBlock, PT_MAIN_WAVES) void wf_main(WfArgs A) {
     const DScene& S = A.S;
     const DCamera& C = A.C;
@@ -1572,8 +1616,8 @@ __global__ __launch_bounds__(kBlock, PT_MAIN_WAVES) void wf_main(WfArgs A) {
         if (need) {
             tm = 0; enters = false;
             best.obj = -1; best.t = 0.0f; best.tri = -1; best.u = best.v = 0.0f;
-            if (first && A.iter0 && A.tile_mask) intersect_list_masked(S, list_mask, P.o, P.d, t_min, t_max, P.rng, best);
-            else intersect_list(S, P.o, P.d, t_min, t_max, P.rng, best);
+            if (first && A.iter0 && A.tile_mask) intersect_list_masked<GV>(S, list_mask, P.o, P.d, t_min, t_max, P.rng, best);
+            else intersect_list<GV>(S, P.o, P.d, t_min, t_max, P.rng, best);
             f3 oo, od, inv; int ti, tend, ttb;
             enters = enter_next_mesh(S, B, tm, P.o, P.d, t_min, t_max, oo, od, inv, ti, tend, ttb, first ? (uint32_t)mesh_word : 0xffffffffu);
             // A ray that hits no object and enters no mesh ends its path at the next shade_ray level
@@ -1670,7 +1714,11 @@ __global__ __launch_bounds__(BS, (BS == 256 ? PT_TRAV_WAVES : 4)) void wf_trav(W
     // the static chunks cover never touches the cursor at all.
     const uint32_t n_q = A.hdr[2];
     const uint32_t n_waves = gridDim.x * ((uint32_t)BS / 64u);
-    const uint32_t chunk = 256u;          // 128 rays per grab: the cursor's round trip shows (trav x3); 1024: long tails (+5 %)
+    // 256 rays per grab (128: the cursor's round trip shows, trav x3; 1024: long tails, +5 %).  A queue too short to give every
+    // wave 256 rays is dealt out evenly instead, in whole waves' worth of 64: 200 k rays are then one walk's time on 3 k waves,
+    // not four walks in a row on 800 (the late passes of a frame, and every pass of a small tile share)
+    uint32_t chunk = 256u;
+    if (n_q < n_waves * 256u) chunk = max(64u, ((n_q + n_waves - 1u) / n_waves + 63u) & ~63u);
     const bool shared_part = n_waves * chunk < n_q;                  // anything beyond the static chunks?
     if (blockIdx.x * ((uint32_t)BS / 64u) * chunk >= n_q) return;       // nothing for this block (then nothing is left over either)
     typename TravBvh<LDS>::type B;
@@ -1926,7 +1974,8 @@ __global__ __launch_bounds__(256, PT_TRAV_WAVES) void wf_trav_f(WfArgs A) {
     const DScene& S = A.S;
     const uint32_t n_q = A.hdr[2];
     const uint32_t n_waves = gridDim.x * 4u;
-    const uint32_t chunk = 256u;
+    uint32_t chunk = 256u;                               // as wf_trav: short queues are dealt out evenly
+    if (n_q < n_waves * 256u) chunk = max(64u, ((n_q + n_waves - 1u) / n_waves + 63u) & ~63u);
     const bool shared_part = n_waves * chunk < n_q;
     if (blockIdx.x * 4u * chunk >= n_q) return;
     cf4_ptr FN = (cf4_ptr)S.fnodes;
@@ -2350,13 +2399,18 @@ hipError_t launch_megakernel(const K1Args& args, uint32_t n_blocks, bool lds, bo
     return hipGetLastError();
 }
 
-hipError_t launch_megakernel_voted(const K1Args& args, uint32_t n_blocks, bool lds, bool sig, bool diag,
+hipError_t launch_megakernel_voted(const K1Args& args, uint32_t n_blocks, bool lds, bool sig, bool diag, bool gv,
                                    size_t lds_bytes, hipStream_t stream) {
     dim3 grid(n_blocks), block(kBlock);
-#define PT_LAUNCH_V(L, G, D) hipLaunchKernelGGL((pt_megakernel_voted<L, G, D>), grid, block, (L) ? lds_bytes : 0, stream, args)
-    if (diag) { if (lds) PT_LAUNCH_V(true, true, true); else PT_LAUNCH_V(false, true, true); }
-    else if (lds) { if (sig) PT_LAUNCH_V(true, true, false); else PT_LAUNCH_V(true, false, false); }
-    else          { if (sig) PT_LAUNCH_V(false, true, false); else PT_LAUNCH_V(false, false, false); }
+    // gv: the scene holds a ConvexVolume whose boundary is not the inline sphere (boundary_hit); the diagnostic form always carries it
+#define PT_LAUNCH_V(L, G, D, V) hipLaunchKernelGGL((pt_megakernel_voted<L, G, D, V>), grid, block, (L) ? lds_bytes : 0, stream, args)
+    if (diag) { if (lds) PT_LAUNCH_V(true, true, true, true); else PT_LAUNCH_V(false, true, true, true); }
+    else if (gv) {
+        if (lds) { if (sig) PT_LAUNCH_V(true, true, false, true); else PT_LAUNCH_V(true, false, false, true); }
+        else     { if (sig) PT_LAUNCH_V(false, true, false, true); else PT_LAUNCH_V(false, false, false, true); }
+    }
+    else if (lds) { if (sig) PT_LAUNCH_V(true, true, false, false); else PT_LAUNCH_V(true, false, false, false); }
+    else          { if (sig) PT_LAUNCH_V(false, true, false, false); else PT_LAUNCH_V(false, false, false, false); }
 #undef PT_LAUNCH_V
     return hipGetLastError();
 }
@@ -2373,10 +2427,15 @@ hipError_t launch_branch(const K1Args& a, uint32_t n_blocks, uint32_t path_sampl
     else hipLaunchKernelGGL((pt_branch<false>), grid, block, 0, stream, a, path_samples);
     return hipGetLastError();
 }
-hipError_t launch_wf_main(const WfArgs& a, uint32_t n_blocks, bool sig, hipStream_t stream) {
+hipError_t launch_wf_main(const WfArgs& a, uint32_t n_blocks, bool sig, bool gv, hipStream_t stream) {
     dim3 grid(n_blocks), block(kBlock);
-    if (sig) hipLaunchKernelGGL((wf_main<false, true>), grid, block, 0, stream, a);
-    else hipLaunchKernelGGL((wf_main<false, false>), grid, block, 0, stream, a);
+    if (gv) {           // the scene holds a ConvexVolume whose boundary is not the inline sphere
+        if (sig) hipLaunchKernelGGL((wf_main<false, true, true>), grid, block, 0, stream, a);
+        else hipLaunchKernelGGL((wf_main<false, false, true>), grid, block, 0, stream, a);
+    } else {
+        if (sig) hipLaunchKernelGGL((wf_main<false, true, false>), grid, block, 0, stream, a);
+        else hipLaunchKernelGGL((wf_main<false, false, false>), grid, block, 0, stream, a);
+    }
     return hipGetLastError();
 }
 // big_lds_enabled: the calling context's record of the > 64 KB dynamic-LDS opt-in.  The attribute belongs to the

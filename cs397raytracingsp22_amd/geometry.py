@@ -70,11 +70,30 @@ class ConvexVolume(Intersectable):   # geometry.rs:495-500
     density: float
 
     def flatten(self, fb):
-        if not isinstance(self.boundary, Sphere):
-            raise abi.MiError(abi.MI_ERR_UNSUPPORTED, "ConvexVolume.boundary must be a Sphere on the GPU path")
+        """`boundary` is `Arc<dyn Intersectable>` (geometry.rs:496): a Sphere travels inline (what every use in the reference
+        is), a Triangle / Plane / StaticMesh as an entry of its typed array that is NOT listed in Scene.objects, a nested Scene
+        (tracing.rs:326) as a run of such entries."""
         v = abi.mi_volume()
-        v.boundary_center = abi.f3(*np.asarray(self.boundary.center, np.float32))
-        v.boundary_radius = float(self.boundary.radius)
+        b = self.boundary
+        if isinstance(b, Sphere):
+            v.boundary_kind = abi.MI_OBJ_SPHERE
+            v.boundary_center = abi.f3(*np.asarray(b.center, np.float32))
+            v.boundary_radius = float(b.radius)
+        elif isinstance(b, (Triangle, Plane, StaticMesh)):
+            v.boundary_kind, v.boundary_index = fb.detached(b)
+        elif hasattr(b, "objects"):                                   # a Scene
+            entries = []
+            for obj in b.objects:
+                if not isinstance(obj, (Sphere, Triangle, Plane, StaticMesh)):
+                    raise abi.MiError(abi.MI_ERR_UNSUPPORTED, "a ConvexVolume or a Scene inside a ConvexVolume boundary")
+                entries.append(fb.detached(obj))
+            v.boundary_kind, v.boundary_index, v.boundary_count = abi.MI_OBJ_SCENE, len(fb.boundary_objects), len(entries)
+            for kind, index in entries:
+                o = abi.mi_object()
+                o.kind, o.index = kind, index
+                fb.boundary_objects.append(o)
+        else:
+            raise abi.MiError(abi.MI_ERR_UNSUPPORTED, "ConvexVolume.boundary: a ConvexVolume inside a boundary is not supported")
         v.density = float(self.density)
         v.phase_material = fb.material(self.phase_function)
         fb.add(abi.MI_OBJ_VOLUME, fb.volumes, v)
@@ -100,6 +119,13 @@ class StaticMesh(Intersectable):     # geometry.rs:127-134
         return StaticMesh(models[0], material, texs, cgmath.identity() if transform is None else transform)
 
     def flatten(self, fb):
+        if id(self) in fb._mesh_ids:          # the same StaticMesh again (Arc sharing, tracing.rs:215): one mi_mesh, another Scene.objects entry
+            o = abi.mi_object()
+            o.kind, o.index = abi.MI_OBJ_MESH, fb._mesh_ids[id(self)]
+            fb.objects.append(o)
+            return
+        fb._mesh_ids[id(self)] = len(fb.meshes)
+        fb.keep.append(self)
         m = abi.mi_mesh()
         me = self.mesh
         if me.normals.size != me.positions.size or me.texcoords.size * 3 != me.positions.size * 2:
@@ -124,8 +150,15 @@ class FlatBuilder:
     def __init__(self):
         self.objects, self.spheres, self.triangles, self.planes = [], [], [], []
         self.volumes, self.meshes, self.materials, self.textures = [], [], [], []
-        self._mat_ids, self._tex_ids = {}, {}
+        self._mat_ids, self._tex_ids, self._mesh_ids = {}, {}, {}
+        self.boundary_objects = []
         self.keep = []
+
+    def detached(self, obj):
+        """Flatten `obj` into its typed array WITHOUT listing it in Scene.objects -> (kind, index)."""
+        obj.flatten(self)
+        o = self.objects.pop()
+        return o.kind, o.index
 
     def add(self, kind, lst, pod):
         o = abi.mi_object()
@@ -176,4 +209,5 @@ class FlatScene:
         d.meshes, d.n_meshes = arr(abi.mi_mesh, fb.meshes)
         d.materials, d.n_materials = arr(abi.mi_material, fb.materials)
         d.textures, d.n_textures = arr(abi.mi_texture, fb.textures)
+        d.boundary_objects, d.n_boundary_objects = arr(abi.mi_object, fb.boundary_objects)
         self.desc = d

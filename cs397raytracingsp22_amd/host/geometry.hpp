@@ -118,6 +118,8 @@ struct SceneBuilder;
 struct Intersectable {
     virtual ~Intersectable() = default;
     virtual void flatten(SceneBuilder& sb) const = 0;
+    // the entries of a nested Scene (tracing.rs:326, `impl Intersectable for Scene`); nullptr for every other implementor
+    virtual const std::vector<std::shared_ptr<const Intersectable>>* scene_objects() const { return nullptr; }
 };
 using IntersectableRef = std::shared_ptr<const Intersectable>;   // Arc<dyn Intersectable + Send + Sync>
 
@@ -126,7 +128,8 @@ struct SceneBuilder {
     std::vector<mi_object> objects; std::vector<mi_sphere> spheres; std::vector<mi_triangle> triangles;
     std::vector<mi_plane> planes; std::vector<mi_volume> volumes; std::vector<mi_mesh> meshes;
     std::vector<mi_material> materials; std::vector<mi_texture> textures;
-    std::map<const Material*, int> mat_ids; std::map<const Texture*, int> tex_ids;
+    std::vector<mi_object> boundary_objects;           // entries of nested Scenes used as ConvexVolume boundaries
+    std::map<const Material*, int> mat_ids; std::map<const Texture*, int> tex_ids; std::map<const void*, int> mesh_ids;
     std::vector<std::shared_ptr<const void>> keep;
 
     int material(const MaterialRef& m) {
@@ -143,6 +146,8 @@ struct SceneBuilder {
         return id;
     }
     void add(int kind, int index) { mi_object o{}; o.kind = kind; o.index = index; objects.push_back(o); }
+    // flatten `obj` into its typed array WITHOUT listing it in Scene.objects (a ConvexVolume's boundary)
+    mi_object detached(const Intersectable& obj);
     mi_scene_desc desc() const {
         mi_scene_desc d{};
         d.objects = objects.data(); d.n_objects = (int)objects.size();
@@ -153,6 +158,7 @@ struct SceneBuilder {
         d.meshes = meshes.data(); d.n_meshes = (int)meshes.size();
         d.materials = materials.data(); d.n_materials = (int)materials.size();
         d.textures = textures.data(); d.n_textures = (int)textures.size();
+        d.boundary_objects = boundary_objects.data(); d.n_boundary_objects = (int)boundary_objects.size();
         return d;
     }
 };
@@ -182,15 +188,12 @@ struct Plane : Intersectable {                         // geometry.rs:468-472
         sb.add(MI_OBJ_PLANE, (int)sb.planes.size()); sb.planes.push_back(p);
     }
 };
+struct StaticMesh;
 struct ConvexVolume : Intersectable {                  // geometry.rs:495-500
-    std::shared_ptr<const Sphere> boundary;            // every use in the reference is a Sphere (tracing.rs:499-516)
+    IntersectableRef boundary;                         // Arc<dyn Intersectable>: a Sphere in every use of the reference (tracing.rs:499-516)
     MaterialRef phase_function; float density;
-    ConvexVolume(std::shared_ptr<const Sphere> b, MaterialRef p, float d) : boundary(std::move(b)), phase_function(std::move(p)), density(d) {}
-    void flatten(SceneBuilder& sb) const override {
-        mi_volume v{}; memcpy(v.boundary_center, boundary->center.data(), 12); v.boundary_radius = boundary->radius;
-        v.density = density; v.phase_material = sb.material(phase_function);
-        sb.add(MI_OBJ_VOLUME, (int)sb.volumes.size()); sb.volumes.push_back(v);
-    }
+    ConvexVolume(IntersectableRef b, MaterialRef p, float d) : boundary(std::move(b)), phase_function(std::move(p)), density(d) {}
+    void flatten(SceneBuilder& sb) const override;
 };
 struct StaticMesh : Intersectable {                    // geometry.rs:127-134
     std::shared_ptr<const Mesh> mesh; MaterialRef material;                 // material may be null (None)
@@ -215,6 +218,9 @@ struct StaticMesh : Intersectable {                    // geometry.rs:127-134
         return sm;                                                              // BVH (:170) is built by mi_scene_upload
     }
     void flatten(SceneBuilder& sb) const override {
+        auto seen = sb.mesh_ids.find(this);           // the same StaticMesh again (Arc sharing, tracing.rs:215): one mi_mesh, another entry
+        if (seen != sb.mesh_ids.end()) { sb.add(MI_OBJ_MESH, seen->second); return; }
+        sb.mesh_ids[this] = (int)sb.meshes.size();
         mi_mesh m{};
         m.positions = mesh->positions.data(); m.normals = mesh->normals.data(); m.texcoords = mesh->texcoords.data();
         m.indices = mesh->indices.data();
@@ -228,5 +234,33 @@ struct StaticMesh : Intersectable {                    // geometry.rs:127-134
         sb.add(MI_OBJ_MESH, (int)sb.meshes.size()); sb.meshes.push_back(m);
     }
 };
+
+inline mi_object SceneBuilder::detached(const Intersectable& obj) {
+    obj.flatten(*this);
+    mi_object o = objects.back(); objects.pop_back();
+    return o;
+}
+inline void ConvexVolume::flatten(SceneBuilder& sb) const {
+    mi_volume v{};
+    if (auto sp = dynamic_cast<const Sphere*>(boundary.get())) {       // inline
+        v.boundary_kind = MI_OBJ_SPHERE; memcpy(v.boundary_center, sp->center.data(), 12); v.boundary_radius = sp->radius;
+    } else if (auto entries = boundary->scene_objects()) {              // a nested Scene
+        std::vector<mi_object> es;
+        for (auto& e : *entries) {
+            if (dynamic_cast<const ConvexVolume*>(e.get()) || e->scene_objects()) throw std::runtime_error("a ConvexVolume or a Scene inside a ConvexVolume boundary is not supported");
+            es.push_back(sb.detached(*e));
+        }
+        v.boundary_kind = MI_OBJ_SCENE; v.boundary_index = (int)sb.boundary_objects.size(); v.boundary_count = (int)es.size();
+        sb.boundary_objects.insert(sb.boundary_objects.end(), es.begin(), es.end());
+    } else if (dynamic_cast<const ConvexVolume*>(boundary.get())) {
+        throw std::runtime_error("a ConvexVolume inside a ConvexVolume boundary is not supported");
+    } else {                                                            // Triangle / Plane / StaticMesh
+        const mi_object o = sb.detached(*boundary);
+        v.boundary_kind = o.kind; v.boundary_index = o.index;
+    }
+    sb.keep.push_back(boundary);
+    v.density = density; v.phase_material = sb.material(phase_function);
+    sb.add(MI_OBJ_VOLUME, (int)sb.volumes.size()); sb.volumes.push_back(v);
+}
 
 }  // namespace cs397

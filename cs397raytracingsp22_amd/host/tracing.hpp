@@ -37,9 +37,11 @@ struct RgbImage { uint32_t width = 0, height = 0; std::vector<uint8_t> data; }; 
 
 inline void mi_check(int rc) { if (rc != MI_OK) throw std::runtime_error(std::string("mi_rt: ") + mi_last_error()); }
 
-struct Scene {                                         // tracing.rs:213-218
+struct Scene : Intersectable {                         // tracing.rs:213-218; `impl Intersectable for Scene` :326
     Camera camera;
     std::vector<IntersectableRef> objects;
+    const std::vector<IntersectableRef>* scene_objects() const override { return &objects; }
+    void flatten(SceneBuilder& sb) const override { for (auto& o : objects) o->flatten(sb); }
     Vec3 point_light_pos{0.0f, 1.0f, 5.0f};            // read by ShadingMode::Phong only (tracing.rs:282,288)
     Vec3 ambient{0.1f, 0.1f, 0.1f};                    // Phong only (:292)
 

@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define MI_RT_ABI_VERSION 3
+#define MI_RT_ABI_VERSION 4
 
 /* ---- status codes (reference: panics via assert!/expect/unwrap, geometry.rs:149-151) ---- */
 typedef enum mi_status {
@@ -78,7 +78,8 @@ typedef enum mi_object_kind {
     MI_OBJ_TRIANGLE = 1,       /* Triangle{a, b, c, material}               geometry.rs:424 */
     MI_OBJ_PLANE    = 2,       /* Plane{point, normal, material}            geometry.rs:468 */
     MI_OBJ_VOLUME   = 3,       /* ConvexVolume{boundary, phase_function, density}      :495 */
-    MI_OBJ_MESH     = 4        /* StaticMesh                                geometry.rs:127 */
+    MI_OBJ_MESH     = 4,       /* StaticMesh                                geometry.rs:127 */
+    MI_OBJ_SCENE    = 5        /* a nested Scene (`impl Intersectable for Scene`, tracing.rs:326) — only as the boundary of a ConvexVolume */
 } mi_object_kind;
 
 /* One entry of Scene.objects (tracing.rs:215), in the reference's order. */
@@ -91,15 +92,22 @@ typedef struct mi_sphere   { float center[3]; float radius; int32_t material; } 
 typedef struct mi_triangle { float a[3]; float b[3]; float c[3]; int32_t material; } mi_triangle;
 typedef struct mi_plane    { float point[3]; float normal[3]; int32_t material; } mi_plane;
 
-/* ConvexVolume (geometry.rs:495-500).  `boundary` is `Arc<dyn Intersectable>` in the
- * reference; every use in the reference (tracing.rs:499-516) and every config is a
- * Sphere, and that is the boundary kind this ABI carries.  The boundary sphere's own
- * material is ignored by the reference ("arbitrary", tracing.rs:503). */
+/* ConvexVolume (geometry.rs:495-500).  `boundary` is `Arc<dyn Intersectable>` in the reference and its intersect_ray is called
+ * twice per ray (geometry.rs:505,508: entry with t in [f32::MIN, f32::MAX], exit from t_entr + 1e-4).  boundary_kind says what it is:
+ *   MI_OBJ_SPHERE (0, what every use in the reference is, tracing.rs:499-516): the sphere given INLINE by boundary_center / _radius;
+ *   MI_OBJ_TRIANGLE, MI_OBJ_PLANE, MI_OBJ_MESH: entry boundary_index of the scene's typed array of that kind;
+ *   MI_OBJ_SCENE: a nested Scene (its closest hit, first entry wins ties, tracing.rs:330-344) = the boundary_count entries of
+ *                 mi_scene_desc.boundary_objects starting at boundary_index, each a Sphere / Triangle / Plane / StaticMesh.
+ * The boundary object need not be listed in Scene.objects; its own material is ignored by the reference ("arbitrary",
+ * tracing.rs:503).  A ConvexVolume or a Scene INSIDE a boundary is MI_ERR_UNSUPPORTED. */
 typedef struct mi_volume {
     float   boundary_center[3];
     float   boundary_radius;
     float   density;
     int32_t phase_material;    /* index of the phase-function material (Isotropic) */
+    int32_t boundary_kind;     /* mi_object_kind, 0 = the inline sphere */
+    int32_t boundary_index;
+    int32_t boundary_count;    /* MI_OBJ_SCENE only */
 } mi_volume;
 
 /* Texture (texture.rs:12-14) after `get_pixel(..).to_rgb()`: tightly packed RGB8,
@@ -137,6 +145,8 @@ typedef struct mi_scene_desc {
     const mi_mesh*     meshes;     int32_t n_meshes;
     const mi_material* materials;  int32_t n_materials;
     const mi_texture*  textures;   int32_t n_textures;
+    /* entries of the nested Scenes that serve as ConvexVolume boundaries (mi_volume.boundary_kind == MI_OBJ_SCENE); may be NULL / 0 */
+    const mi_object*   boundary_objects;  int32_t n_boundary_objects;
     /* Scene.point_light_pos / Scene.ambient (tracing.rs:216-217): read by ShadingMode::Phong only */
     float              point_light_pos[3];
     float              ambient[3];

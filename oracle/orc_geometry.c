@@ -283,16 +283,51 @@ int orc_plane_intersect(const orc_scene* s, const mi_plane* pl, const orc_ray* r
 }
 
 /* ---- ConvexVolume (geometry.rs:501-526) ---- */
+/* `self.boundary.intersect_ray(ray, t_min, t_max)` (:505,508) for the boundary kinds the ABI carries: dyn dispatch over
+ * Sphere (inline), Triangle, Plane, StaticMesh, or a nested Scene (tracing.rs:327-346: closest hit, strict `<`). */
+static int boundary_entry_intersect(const orc_scene* s, int kind, int index, const orc_ray* ray, float t_min, float t_max,
+                                    orc_path* p, orc_rayhit* out) {
+    switch (kind) {
+    case MI_OBJ_SPHERE:   return orc_sphere_intersect(s, &s->spheres[index], ray, t_min, t_max, out);
+    case MI_OBJ_TRIANGLE: return orc_triangle_intersect(s, &s->triangles[index], ray, t_min, t_max, out);
+    case MI_OBJ_PLANE:    return orc_plane_intersect(s, &s->planes[index], ray, t_min, t_max, out);
+    case MI_OBJ_MESH:     return orc_mesh_intersect(s, &s->meshes[index], ray, t_min, t_max, p, out);
+    default: return 0;
+    }
+}
+static int boundary_intersect(const orc_scene* s, const mi_volume* vo, const orc_ray* ray, float t_min, float t_max,
+                              orc_path* p, orc_rayhit* out) {
+    if (vo->boundary_kind == MI_OBJ_SPHERE) {
+        mi_sphere boundary;
+        boundary.center[0] = vo->boundary_center[0]; boundary.center[1] = vo->boundary_center[1]; boundary.center[2] = vo->boundary_center[2];
+        boundary.radius = vo->boundary_radius; boundary.material = -1;   /* boundary material is never read (:503 "arbitrary") */
+        return orc_sphere_intersect(NULL, &boundary, ray, t_min, t_max, out);
+    }
+    /* the counters describe Scene.objects' own work: a boundary's mesh walk is not counted */
+    orc_path q = *p; q.cnt = NULL;
+    if (vo->boundary_kind == MI_OBJ_SCENE) {                            /* impl Intersectable for Scene, tracing.rs:327-346 */
+        int have_best = 0; orc_rayhit best_hit;
+        for (int k = 0; k < vo->boundary_count; k++) {
+            const mi_object* e = &s->boundary_objects[vo->boundary_index + k];
+            orc_rayhit hit;
+            if (boundary_entry_intersect(s, e->kind, e->index, ray, t_min, t_max, &q, &hit)) {
+                if (!have_best) { best_hit = hit; have_best = 1; }      /* :333 */
+                else if (hit.distance < best_hit.distance) best_hit = hit;   /* :335-336 */
+            }
+        }
+        if (have_best) *out = best_hit;
+        return have_best;
+    }
+    return boundary_entry_intersect(s, vo->boundary_kind, vo->boundary_index, ray, t_min, t_max, &q, out);
+}
+
 int orc_volume_intersect(const orc_scene* s, const mi_volume* vo, const orc_ray* ray, float t_min, float t_max,
                          orc_path* p, orc_rayhit* out) {
     const float F32_MIN = -3.40282347e+38f, F32_MAX = 3.40282347e+38f;
-    mi_sphere boundary;
-    boundary.center[0] = vo->boundary_center[0]; boundary.center[1] = vo->boundary_center[1]; boundary.center[2] = vo->boundary_center[2];
-    boundary.radius = vo->boundary_radius; boundary.material = -1;   /* boundary material is never read (:503 "arbitrary") */
     orc_rayhit hit_entr, hit_exit;
-    if (!orc_sphere_intersect(NULL, &boundary, ray, F32_MIN, F32_MAX, &hit_entr)) return 0;        /* :505-506 */
+    if (!boundary_intersect(s, vo, ray, F32_MIN, F32_MAX, p, &hit_entr)) return 0;                 /* :505-506 */
     float t_entr = hit_entr.distance;                                                             /* :507 */
-    if (!orc_sphere_intersect(NULL, &boundary, ray, t_entr + 0.0001f, F32_MAX, &hit_exit)) return 0;   /* :508-509 */
+    if (!boundary_intersect(s, vo, ray, t_entr + 0.0001f, F32_MAX, p, &hit_exit)) return 0;        /* :508-509 */
     float t_exit = hit_exit.distance;                                 /* :510 */
     if (t_exit < t_min || t_entr > t_max) return 0;                   /* :512 */
     float t_start = fmaxf(t_entr, t_min);                             /* :513 */

@@ -57,6 +57,7 @@ struct orc_scene {
     orc_mesh*    meshes;    int n_meshes;
     mi_material* materials; int n_materials;
     mi_texture*  textures;  int n_textures;   /* rgb deep-copied */
+    mi_object*   boundary_objects; int n_boundary_objects;   /* entries of nested Scenes used as ConvexVolume boundaries */
 };
 
 /* per-path context: RNG stream, signature accumulator, counters */

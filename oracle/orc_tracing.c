@@ -328,6 +328,8 @@ int orc_scene_create(const mi_scene_desc* d, orc_scene** out) {
     s->n_planes = d->n_planes;       s->planes = (mi_plane*)dup_mem(d->planes, sizeof(mi_plane) * (size_t)d->n_planes);
     s->n_volumes = d->n_volumes;     s->volumes = (mi_volume*)dup_mem(d->volumes, sizeof(mi_volume) * (size_t)d->n_volumes);
     s->n_materials = d->n_materials; s->materials = (mi_material*)dup_mem(d->materials, sizeof(mi_material) * (size_t)d->n_materials);
+    s->n_boundary_objects = d->boundary_objects ? d->n_boundary_objects : 0;
+    s->boundary_objects = (mi_object*)dup_mem(d->boundary_objects, sizeof(mi_object) * (size_t)s->n_boundary_objects);
     s->n_textures = d->n_textures;   s->textures = (mi_texture*)dup_mem(d->textures, sizeof(mi_texture) * (size_t)d->n_textures);
     for (int i = 0; i < s->n_textures; i++)
         s->textures[i].rgb = (const uint8_t*)dup_mem(d->textures[i].rgb, (size_t)d->textures[i].width * d->textures[i].height * 3);
@@ -359,6 +361,24 @@ int orc_scene_create(const mi_scene_desc* d, orc_scene** out) {
         }
         if (o->index < 0 || o->index >= n) { orc_scene_destroy(s); return MI_ERR_INVALID; }
     }
+    for (int i = 0; i < s->n_volumes; i++) {                           /* ConvexVolume.boundary: Arc<dyn Intersectable> */
+        const mi_volume* v = &s->volumes[i];
+        int first = 0, count = 1; const mi_object* entries = NULL; mi_object one;
+        if (v->boundary_kind == MI_OBJ_SPHERE) continue;                /* the inline sphere */
+        if (v->boundary_kind == MI_OBJ_SCENE) {
+            first = v->boundary_index; count = v->boundary_count; entries = s->boundary_objects;
+            if (first < 0 || count < 0 || first + count > s->n_boundary_objects) { orc_scene_destroy(s); return MI_ERR_INVALID; }
+        } else { one.kind = v->boundary_kind; one.index = v->boundary_index; entries = &one; }
+        for (int k = 0; k < count; k++) {
+            const mi_object* e = &entries[first + k]; int n = -1;
+            switch (e->kind) {
+            case MI_OBJ_SPHERE: n = s->n_spheres; break;   case MI_OBJ_TRIANGLE: n = s->n_triangles; break;
+            case MI_OBJ_PLANE: n = s->n_planes; break;     case MI_OBJ_MESH: n = s->n_meshes; break;
+            default: orc_scene_destroy(s); return MI_ERR_UNSUPPORTED;   /* a volume or a scene inside a boundary */
+            }
+            if (e->index < 0 || e->index >= n) { orc_scene_destroy(s); return MI_ERR_INVALID; }
+        }
+    }
     *out = s;
     return MI_OK;
 }
@@ -372,7 +392,7 @@ void orc_scene_destroy(orc_scene* s) {
     }
     for (int i = 0; i < s->n_textures; i++) free((void*)s->textures[i].rgb);
     free(s->meshes); free(s->objects); free(s->spheres); free(s->triangles); free(s->planes);
-    free(s->volumes); free(s->materials); free(s->textures);
+    free(s->volumes); free(s->materials); free(s->textures); free(s->boundary_objects);
     free(s);
 }
 

@@ -10,7 +10,8 @@ use std::os::raw::{c_char, c_int, c_void};
 #[repr(C)] #[derive(Clone, Copy)] pub struct mi_sphere { pub center: [f32; 3], pub radius: f32, pub material: i32 }
 #[repr(C)] #[derive(Clone, Copy)] pub struct mi_triangle { pub a: [f32; 3], pub b: [f32; 3], pub c: [f32; 3], pub material: i32 }
 #[repr(C)] #[derive(Clone, Copy)] pub struct mi_plane { pub point: [f32; 3], pub normal: [f32; 3], pub material: i32 }
-#[repr(C)] #[derive(Clone, Copy)] pub struct mi_volume { pub boundary_center: [f32; 3], pub boundary_radius: f32, pub density: f32, pub phase_material: i32 }
+#[repr(C)] #[derive(Clone, Copy)] pub struct mi_volume { pub boundary_center: [f32; 3], pub boundary_radius: f32, pub density: f32, pub phase_material: i32,
+    pub boundary_kind: i32, pub boundary_index: i32, pub boundary_count: i32 }   // 0 = the inline sphere; else Triangle / Plane / StaticMesh / nested Scene
 #[repr(C)] #[derive(Clone, Copy)] pub struct mi_texture { pub width: i32, pub height: i32, pub rgb: *const u8 }
 #[repr(C)] #[derive(Clone, Copy)] pub struct mi_mesh {
     pub positions: *const f32, pub normals: *const f32, pub texcoords: *const f32, pub indices: *const u32,
@@ -22,6 +23,7 @@ use std::os::raw::{c_char, c_int, c_void};
     pub triangles: *const mi_triangle, pub n_triangles: i32, pub planes: *const mi_plane, pub n_planes: i32,
     pub volumes: *const mi_volume, pub n_volumes: i32, pub meshes: *const mi_mesh, pub n_meshes: i32,
     pub materials: *const mi_material, pub n_materials: i32, pub textures: *const mi_texture, pub n_textures: i32,
+    pub boundary_objects: *const mi_object, pub n_boundary_objects: i32,   // entries of nested Scenes used as ConvexVolume boundaries
     pub point_light_pos: [f32; 3], pub ambient: [f32; 3],   // Scene.point_light_pos / ambient (tracing.rs:216-217), Phong only
 }
 #[repr(C)] pub struct mi_camera_desc {
@@ -37,7 +39,7 @@ pub const MI_OPT_NO_TILE_MASKS: u32 = 1; pub const MI_OPT_REFERENCE_WALK: u32 = 
 
 #[link(name = "mi_rt")]
 extern "C" {
-    // every entry point of include/mi_rt.h (ABI 3), in header order
+    // every entry point of include/mi_rt.h (ABI 4), in header order
     pub fn mi_ctx_create(device: c_int, out: *mut *mut mi_ctx) -> c_int;
     pub fn mi_ctx_destroy(ctx: *mut mi_ctx);
     pub fn mi_scene_upload(ctx: *mut mi_ctx, scene: *const mi_scene_desc) -> c_int;
@@ -69,7 +71,7 @@ extern "C" {
     pub fn mi_multi_render(m: *mut mi_multi, cam: *const mi_camera_desc, opts: *const mi_render_opts,
                            out_rgb_f32: *mut f32, out_rgb_u8: *mut u8, out_sig: *mut u32, stats: *mut mi_stats) -> c_int;
     pub fn mi_last_error() -> *const c_char;
-    pub fn mi_abi_version() -> c_int;           // 3: assert at start-up that header and library agree
+    pub fn mi_abi_version() -> c_int;           // 4: assert at start-up that header and library agree
 }
 
 /// Collected in `Scene.objects` order by the additive trait method
@@ -79,6 +81,7 @@ extern "C" {
 pub struct SceneBuilder {
     pub objects: Vec<mi_object>, pub spheres: Vec<mi_sphere>, pub triangles: Vec<mi_triangle>, pub planes: Vec<mi_plane>,
     pub volumes: Vec<mi_volume>, pub meshes: Vec<mi_mesh>, pub materials: Vec<mi_material>, pub textures: Vec<mi_texture>,
+    pub boundary_objects: Vec<mi_object>,
 }
 impl SceneBuilder {
     pub fn desc(&self) -> mi_scene_desc {
@@ -91,6 +94,7 @@ impl SceneBuilder {
             meshes: self.meshes.as_ptr(), n_meshes: self.meshes.len() as i32,
             materials: self.materials.as_ptr(), n_materials: self.materials.len() as i32,
             textures: self.textures.as_ptr(), n_textures: self.textures.len() as i32,
+            boundary_objects: self.boundary_objects.as_ptr(), n_boundary_objects: self.boundary_objects.len() as i32,
             point_light_pos: [0.0, 1.0, 5.0], ambient: [0.1, 0.1, 0.1],   // caller overwrites from Scene
         }
     }

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     lib = abi.load()
     for name in declared_functions():
         assert hasattr(lib, name), name
-    assert lib.mi_abi_version() == abi.MI_RT_ABI_VERSION == 3
+    assert lib.mi_abi_version() == abi.MI_RT_ABI_VERSION == 4
 
 
 def test_ctypes_layout_matches_c(tmp_path):
@@ -88,3 +88,4 @@ def test_rust_shim_declares_every_entry_point():
     declared = set(re.findall(r"pub fn (mi_[a-z_0-9]+)\(", src))
     assert declared == set(declared_functions())
     assert "pub flags: u32" in src and "pub max_state_bytes: u64" in src          # mi_render_opts, ABI 3
+    assert "pub boundary_kind: i32" in src and "pub boundary_objects: *const mi_object" in src      # ABI 4

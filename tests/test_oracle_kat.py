@@ -445,3 +445,74 @@ def test_phong_scatter_draw_comes_after_the_shadow_ray(orc):
         diff += int(not np.array_equal(ca, cb))
     # the thin fog almost never scatters (shadow weight stays 1) but shifts the stream: some lobe choices flip
     assert 0 < diff < 64
+
+
+# ---------------------------------------------------------------- ConvexVolume over any `Arc<dyn Intersectable>` (geometry.rs:496)
+def cube_mesh(lo=-1.0, hi=1.0):
+    """An axis-aligned cube as 12 triangles, one vertex set per triangle (tobj single_index layout), outward normals."""
+    c = [(lo, lo, lo), (hi, lo, lo), (hi, hi, lo), (lo, hi, lo), (lo, lo, hi), (hi, lo, hi), (hi, hi, hi), (lo, hi, hi)]
+    quads = [(0, 3, 2, 1), (4, 5, 6, 7), (0, 1, 5, 4), (2, 3, 7, 6), (1, 2, 6, 5), (0, 4, 7, 3)]
+    pos, nrm, uv, idx = [], [], [], []
+    for q in quads:
+        for tri in ((q[0], q[1], q[2]), (q[0], q[2], q[3])):
+            p = [np.float32(c[k]) for k in tri]
+            n = np.cross(p[1] - p[0], p[2] - p[0]); n = n / np.linalg.norm(n)
+            for j in range(3):
+                pos.append(p[j]); nrm.append(n); uv.append((float(j == 1), float(j == 2))); idx.append(len(idx))
+    return objload.Mesh(np.float32(pos), np.float32(nrm), np.float32(uv), np.uint32(idx))
+
+
+def cube_triangles(lo=-1.0, hi=1.0):
+    m = cube_mesh(lo, hi)
+    p = m.positions.reshape(-1, 3, 3)
+    return [Triangle(tuple(t[0]), tuple(t[1]), tuple(t[2]), GREY) for t in p]
+
+
+def test_volume_boundary_static_mesh_and_nested_scene(orc):
+    """geometry.rs:505-509 on a boundary that is not a sphere: entry = the boundary's closest hit over [f32::MIN, f32::MAX], exit
+    = its closest hit from t_entr + 1e-4.  A cube [-1,1]^3 seen from z = 4 along -z: t_entr = 3, t_exit = 5; with an enormous
+    density the free flight is ~0, so the scatter point sits at t_start = max(t_entr, t_min)."""
+    phase = Isotropic(albedo=(1, 1, 1))
+    as_mesh = ConvexVolume(StaticMesh(cube_mesh(), GREY, [None] * 5, cgmath.identity()), phase, 1e9)
+    as_scene = ConvexVolume(Scene(Camera(), cube_triangles()), phase, 1e9)
+    for vol in (as_mesh, as_scene):
+        s = oscene(orc, [vol])
+        h = s.intersect((0.25, 0.125, 4.0), (0, 0, -1))
+        assert h.hit and 3.0 <= h.distance <= 3.0 + 1e-5 and np.allclose(h.normal[:], 0.0)
+        h = s.intersect((0.25, 0.125, 0.0), (0, 0, -1))                    # from inside: t_entr = -1 (behind), t_start = t_min
+        assert h.hit and 0.001 <= h.distance <= 0.001 + 1e-5
+        assert not s.intersect((3.0, 0.0, 4.0), (0, 0, -1)).hit            # passes beside the cube
+        h = s.intersect((0.25, 0.125, 4.0), (0, 0, -2))                    # parametric distances: |d| = 2 halves t
+        assert h.hit and 1.5 <= h.distance <= 1.5 + 1e-5
+    # the transform of a StaticMesh boundary applies (geometry.rs:304): the cube moved to z in [-11, -9]
+    moved = ConvexVolume(StaticMesh(cube_mesh(), GREY, [None] * 5, cgmath.from_translation((0, 0, -10))), phase, 1e9)
+    h = oscene(orc, [moved]).intersect((0, 0.125, 0.25), (0, 0, -1))
+    assert h.hit and abs(h.distance - 9.25) < 1e-4
+
+
+def test_volume_boundary_single_triangle_or_plane_never_scatters(orc):
+    """One Triangle or one Plane is hit once by a line: the exit query (from t_entr + 1e-4) finds nothing and
+    ConvexVolume::intersect_ray returns None before it draws its random number (geometry.rs:509)."""
+    phase = Isotropic(albedo=(1, 1, 1))
+    tri = Triangle((-5, -5, -3), (5, -5, -3), (0, 5, -3), GREY)
+    pl = Plane((0, 0, -3), (0, 0, 1), GREY)
+    cam = Camera(path_depth=2, aa_sample_count=1, screen_width=8, screen_height=8)
+    _, _, base, _ = oscene(orc, [], cam).render(cam, seed=2)
+    for b in (tri, pl):
+        s = oscene(orc, [ConvexVolume(b, phase, 1e9)], cam)
+        assert not s.intersect((0, 0, 0), (0, 0, -1)).hit
+        _, _, sig, _ = s.render(cam, seed=2)
+        assert np.array_equal(sig, base)                                   # no draw: the RNG state at the end of every path is unchanged
+
+
+def test_same_static_mesh_twice_in_scene_objects(orc):
+    """Arc sharing (tracing.rs:215): the SAME StaticMesh listed twice gives the same hits twice; the first entry keeps the tie
+    (tracing.rs:335), so the image equals the one with the mesh listed once and the hit names object 0."""
+    m = StaticMesh(cube_mesh(), GREY, [None] * 5, cgmath.from_translation((0, 1, -4)))
+    cam = Camera(path_depth=3, aa_sample_count=4, screen_width=24, screen_height=24)
+    flat2 = Scene(cam, [m, m]).flatten()
+    assert flat2.desc.n_meshes == 1 and flat2.desc.n_objects == 2
+    a, _, _, _ = orc.OracleScene(flat2).render(cam, seed=3)
+    b, _, _, _ = oscene(orc, [m], cam).render(cam, seed=3)
+    assert np.array_equal(a, b)
+    assert orc.OracleScene(flat2).intersect((0, 1, 0), (0, 0, -1)).object == 0
