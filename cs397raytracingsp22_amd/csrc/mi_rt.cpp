@@ -40,6 +40,7 @@ hipError_t launch_wf_main(const WfArgs& a, uint32_t n_blocks, bool sig, bool gv,
 hipError_t launch_phong(const K1Args& a, uint32_t n_blocks, bool sig, hipStream_t stream);
 hipError_t launch_branch(const K1Args& a, uint32_t n_blocks, uint32_t path_samples, bool sig, hipStream_t stream);
 hipError_t launch_wf_trav(const WfArgs& a, uint32_t n_blocks, int lds_mode, size_t lds_bytes, bool* big_lds_enabled, hipStream_t stream);
+hipError_t launch_wf_trav_i(const WfArgs& a, uint32_t n_blocks, size_t lds_bytes, bool* big_lds_enabled, hipStream_t stream);
 hipError_t launch_wf_trav_f(const WfArgs& a, uint32_t n_blocks, hipStream_t stream);
 hipError_t launch_wf_replay(const WfArgs& a, uint32_t n_blocks, hipStream_t stream);
 hipError_t launch_wf_prefix(uint32_t* out_count, uint32_t* trav_count, uint32_t* in_count, uint32_t* in_blkpfx,
@@ -102,7 +103,7 @@ struct mi_ctx {
     uint32_t lds_bytes = 0;                  // bytes needed to stage nodes + tris, 0 = no meshes
     // per live mesh (Scene.objects order): end of its nodes in the node pool, does the two-stage bound apply to it at all,
     // is it walked two-stage by default (qualifies and large enough for the F-tree to pay)
-    std::vector<int> mesh_node_end, mesh_e2_end; std::vector<uint8_t> mesh_qualifies, mesh_default_ts;
+    std::vector<int> mesh_node_end, mesh_e2_end, mesh_inode_end; std::vector<uint8_t> mesh_qualifies, mesh_default_ts;
     void* d_cand = nullptr; size_t cand_bytes = 0;           // two-stage candidates [cap][kCandMax] {t, key}
     void* d_cand_hdr = nullptr; size_t cand_hdr_bytes = 0;   // [cap] {pos, count | flags}
 
@@ -116,6 +117,7 @@ struct mi_ctx {
     float point_light_pos[3] = {0.0f, 1.0f, 5.0f}, ambient[3] = {0.1f, 0.1f, 0.1f};   // Scene fields read by Phong
     hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;     // mi_render's whole-call timer
     bool big_lds_enabled = false;                    // wf_trav<2,1024>'s > 64 KB dynamic-LDS opt-in, set on THIS context's device
+    bool big_lds_enabled_i = false;                  // the same for wf_trav_i<1024>
     // wavefront pipeline buffers
     void* d_wf_a = nullptr; size_t wf_a_bytes = 0;   // path state ping
     void* d_wf_b = nullptr; size_t wf_b_bytes = 0;   // path state pong
@@ -285,9 +287,9 @@ extern "C" int mi_scene_upload(mi_ctx* c, const mi_scene_desc* d) {
     std::vector<DMaterial> mats((size_t)d->n_materials);
     std::vector<DMesh> meshes((size_t)d->n_meshes);
     std::vector<DMeshF> meshf((size_t)d->n_meshes);
-    struct MeshBuild { std::vector<float> nodes, fnodes, ftris; bool qualifies = false, default_ts = false; };
+    struct MeshBuild { std::vector<float> nodes, fnodes, ftris; bool qualifies = false, default_ts = false; int inode_end = 0; };
     std::vector<MeshBuild> mb((size_t)d->n_meshes);
-    std::vector<float> nodes, tris, fnodes, ftris, e2s;
+    std::vector<float> nodes, tris, fnodes, ftris, e2s, inodes, lnodes;
     std::vector<DTriAttr> attrs;
     std::vector<DTexture> texs((size_t)d->n_textures);
     std::vector<uint8_t> texels;
@@ -467,6 +469,36 @@ extern "C" int mi_scene_upload(mi_ctx* c, const mi_scene_desc* d) {
                 const float rec[4] = { T[8], T[9], T[10], 0.0f };
                 e2s.insert(e2s.end(), rec, rec + 4);
             }
+            // the same tree with interior nodes and leaves in separate pools and explicit links (pt_device.h DScene.inodes)
+            {
+                const int n_local = (int)(B.nodes.size() / 8);
+                const int ibase = (int)(inodes.size() / 8), lbase = (int)(lnodes.size() / 12);
+                std::vector<int32_t> id((size_t)n_local);
+                int ni = 0, nl = 0;
+                for (int j = 0; j < n_local; j++) {
+                    int tri; memcpy(&tri, &B.nodes[(size_t)j * 8 + 7], 4);
+                    id[(size_t)j] = tri < 0 ? ibase + ni++ : ~(lbase + nl++);
+                }
+                auto id_of = [&](int j) -> int32_t { return j >= n_local ? kIdEnd : id[(size_t)j]; };
+                for (int j = 0; j < n_local; j++) {
+                    const float* N = &B.nodes[(size_t)j * 8];
+                    int sk, tri; memcpy(&sk, &N[3], 4); memcpy(&tri, &N[7], 4);
+                    if (tri < 0) {
+                        float rec[8] = { N[0], N[1], N[2], 0.0f, N[4], N[5], N[6], 0.0f };
+                        const int32_t miss = id_of(sk - nbase), hit = id_of(j + 1);
+                        memcpy(&rec[3], &miss, 4); memcpy(&rec[7], &hit, 4);
+                        inodes.insert(inodes.end(), rec, rec + 8);
+                    } else {
+                        const float* T = &tris[((size_t)M.tri_begin + (size_t)tri) * 12];
+                        float rec[12] = { T[0], T[1], T[2], 0.0f, T[4], T[5], T[6], 0.0f, T[8], T[9], T[10], 0.0f };
+                        const int32_t next = id_of(j + 1);
+                        memcpy(&rec[3], &next, 4); memcpy(&rec[7], &tri, 4);
+                        lnodes.insert(lnodes.end(), rec, rec + 12);
+                    }
+                }
+                M.i_root = id_of(0);
+                B.inode_end = (int)(inodes.size() / 8);
+            }
             nodes.insert(nodes.end(), B.nodes.begin(), B.nodes.end());
             M.node_end = (int)(nodes.size() / 8);
             for (size_t k = 0; k < B.fnodes.size(); k += 8) { int sk; memcpy(&sk, &B.fnodes[k + 3], 4); sk += fbase; memcpy(&B.fnodes[k + 3], &sk, 4); }
@@ -575,7 +607,7 @@ extern "C" int mi_scene_upload(mi_ctx* c, const mi_scene_desc* d) {
     // walks), then one per boundary mesh (reached only through a ConvexVolume's boundary record).
     std::vector<DMesh> live;
     std::vector<DMeshF> livef;
-    c->mesh_node_end.clear(); c->mesh_e2_end.clear(); c->mesh_qualifies.clear(); c->mesh_default_ts.clear();
+    c->mesh_node_end.clear(); c->mesh_e2_end.clear(); c->mesh_inode_end.clear(); c->mesh_qualifies.clear(); c->mesh_default_ts.clear();
     for (int i = 0; i < d->n_objects; i++)
         if (objs[(size_t)i].kind == OBJ_MESH) {
             int r = objs[(size_t)i].ref; objs[(size_t)i].ref = (int)live.size();
@@ -583,6 +615,7 @@ extern "C" int mi_scene_upload(mi_ctx* c, const mi_scene_desc* d) {
             live.back().object_index = i;
             c->mesh_node_end.push_back(meshes[(size_t)r].node_end);
             c->mesh_e2_end.push_back(meshes[(size_t)r].e2_begin + meshes[(size_t)r].n_tris);
+            c->mesh_inode_end.push_back(mb[(size_t)r].inode_end);
             c->mesh_qualifies.push_back(mb[(size_t)r].qualifies ? 1 : 0); c->mesh_default_ts.push_back(mb[(size_t)r].default_ts ? 1 : 0);
         }
     const size_t n_scene_meshes = live.size();
@@ -647,7 +680,9 @@ extern "C" int mi_scene_upload(mi_ctx* c, const mi_scene_desc* d) {
     size_t off_ftris = align(off_fnodes + fnodes.size() * 4 + 32);
     size_t off_nodes = align(off_ftris + ftris.size() * 4 + 48);
     size_t off_e2 = align(off_nodes + nodes.size() * 4);
-    size_t off_tris = align(off_e2 + e2s.size() * 4 + 16);
+    size_t off_inodes = align(off_e2 + e2s.size() * 4 + 16);
+    size_t off_lnodes = align(off_inodes + inodes.size() * 4 + 32);
+    size_t off_tris = align(off_lnodes + lnodes.size() * 4 + 48);
     size_t off_attr = align(off_tris + tris.size() * 4);
     size_t off_tex = align(off_attr + attrs.size() * sizeof(DTriAttr));
     size_t off_texel = align(off_tex + texs.size() * sizeof(DTexture));
@@ -665,6 +700,8 @@ extern "C" int mi_scene_upload(mi_ctx* c, const mi_scene_desc* d) {
     put(off_ftris, ftris.data(), ftris.size() * 4);
     put(off_nodes, nodes.data(), nodes.size() * 4);
     put(off_e2, e2s.data(), e2s.size() * 4);
+    put(off_inodes, inodes.data(), inodes.size() * 4);
+    put(off_lnodes, lnodes.data(), lnodes.size() * 4);
     put(off_tris, tris.data(), tris.size() * 4);
     put(off_attr, attrs.data(), attrs.size() * sizeof(DTriAttr));
     put(off_tex, texs.data(), texs.size() * sizeof(DTexture));
@@ -690,6 +727,8 @@ extern "C" int mi_scene_upload(mi_ctx* c, const mi_scene_desc* d) {
     c->S.n_fnodes = (int)(fnodes.size() / 8);
     c->S.nodes = (const float*)(b + off_nodes);
     c->S.e2s = (const float*)(b + off_e2);
+    c->S.inodes = (const float*)(b + off_inodes);
+    c->S.lnodes = (const float*)(b + off_lnodes);
     c->S.tris = (const float*)(b + off_tris);
     c->S.triattr = (const DTriAttr*)(b + off_attr);
     c->S.textures = (const DTexture*)(b + off_tex);
@@ -1067,27 +1106,37 @@ static int render_tiles_wavefront(mi_ctx* c, const K1Args& k, const mi_camera_de
     // teapot 15 KB -> 8 blocks per CU; 122.6 ms vs 126.0 ms for mode 1 on cfg2 1080p/256), 1 = nodes +
     // triangles (what the megakernels stage), 0 = everything from global memory.  The LDS window is the head of the node
     // pool up to the last tree wf_trav walks (the scene compiler places those trees first).
-    int ref_nodes = 0, ref_e2 = 0;
+    int ref_nodes = 0, ref_e2 = 0, ref_inodes = 0;
     for (size_t m = 0; m < c->mesh_node_end.size(); m++) if (m >= 32 || ((ref_mask >> m) & 1u)) {     // meshes 32, 33, ... have no mask bit: always walked here
         ref_nodes = std::max(ref_nodes, c->mesh_node_end[m]); ref_e2 = std::max(ref_e2, c->mesh_e2_end[m]);
+        ref_inodes = std::max(ref_inodes, c->mesh_inode_end[m]);
     }
     // LDS image of a walker block: the nodes (leaves carry a and e1 of their triangle) + the triangles' e2 vectors
     const size_t node_bytes = (size_t)ref_nodes * 32 + (size_t)ref_e2 * 16;
-    // 3 = the image needs most of a CU's 160 KB: ONE 1024-thread block per CU (16 waves)
+    const size_t inode_bytes = (size_t)ref_inodes * 32;               // wf_trav_i: the interior nodes only
+    // 3 = the image needs most of a CU's 160 KB: ONE 1024-thread block per CU (16 waves).  4 = wf_trav_i: interior nodes in LDS, leaves
+    // from global memory — chosen over 3 whenever two of its blocks fit a CU (8 waves per SIMD instead of 4), and the only LDS mode
+    // left for images beyond 156 KB whose interior nodes still fit
     int trav_lds_mode = 0;
-    if (ref_nodes > 0 && !c->tune.global_bvh) trav_lds_mode = node_bytes <= 64u * 1024u ? 2 : (node_bytes <= 156u * 1024u ? 3 : 0);
+    if (ref_nodes > 0 && !c->tune.global_bvh) {
+        if (node_bytes <= 64u * 1024u) trav_lds_mode = 2;
+        else if (inode_bytes <= 78u * 1024u) trav_lds_mode = 4;
+        else if (node_bytes <= 156u * 1024u) trav_lds_mode = 3;
+        else if (inode_bytes <= 156u * 1024u) trav_lds_mode = 4;
+    }
     if (c->tune.trav_lds >= 0) {
         const int m = c->tune.trav_lds;
-        if (m == 0 || (m == 2 && node_bytes <= 64u * 1024u) || (m == 3 && node_bytes <= 156u * 1024u)) trav_lds_mode = m;
+        if (m == 0 || (m == 2 && node_bytes <= 64u * 1024u) || (m == 3 && node_bytes <= 156u * 1024u) || (m == 4 && inode_bytes <= 156u * 1024u && ref_nodes > 0)) trav_lds_mode = m;
     }
-    const size_t trav_lds_bytes = trav_lds_mode >= 2 ? node_bytes : 0;
-    a.R.lds_nodes = trav_lds_mode ? (uint32_t)ref_nodes : 0;
-    a.R.lds_tris = trav_lds_mode ? (uint32_t)ref_e2 : 0;          // e2 entries staged behind the nodes
+    const size_t trav_lds_bytes = trav_lds_mode == 4 ? inode_bytes : (trav_lds_mode >= 2 ? node_bytes : 0);
+    a.R.lds_nodes = trav_lds_mode == 4 ? (uint32_t)ref_inodes : (trav_lds_mode ? (uint32_t)ref_nodes : 0);
+    a.R.lds_tris = (trav_lds_mode == 2 || trav_lds_mode == 3) ? (uint32_t)ref_e2 : 0;          // e2 entries staged behind the nodes
     a.cand = (uint2*)c->d_cand; a.cand_hdr = (uint2*)c->d_cand_hdr;
     float4* bufs[2] = { (float4*)c->d_wf_a, (float4*)c->d_wf_b };
     uint32_t trav_bpc = 6;                  // resident blocks per CU: bounded by LDS (160 KB) and by 8 waves/SIMD
     if (trav_lds_mode == 2) { trav_bpc = (uint32_t)((160u * 1024u) / (node_bytes ? node_bytes : 1)); if (trav_bpc > 8) trav_bpc = 8; if (trav_bpc < 2) trav_bpc = 2; }
     if (trav_lds_mode == 3) trav_bpc = 1;
+    if (trav_lds_mode == 4) trav_bpc = inode_bytes <= 78u * 1024u ? 2 : 1;
     if (c->tune.trav_bpc > 0) trav_bpc = (uint32_t)c->tune.trav_bpc;
     const uint32_t trav_blocks = (uint32_t)c->n_cus * trav_bpc;
     const uint32_t travf_blocks = (uint32_t)c->n_cus * 6u, replay_blocks = (uint32_t)c->n_cus * 8u;
@@ -1218,7 +1267,8 @@ static int render_tiles_wavefront(mi_ctx* c, const K1Args& k, const mi_camera_de
             // into the hit record (strictly closer wins, ties go to the lower Scene.objects index: order-independent)
             if (ref_mask || c->S.n_meshes > 32) {      // meshes 32, 33, ... have no mask bit: they always take the reference walk
                 a.trav_mask = ref_mask;
-                WF_TIMED(1, launch_wf_trav(a, trav_blocks, trav_lds_mode, trav_lds_bytes, &c->big_lds_enabled, stream));
+                if (trav_lds_mode == 4) WF_TIMED(1, launch_wf_trav_i(a, trav_blocks, trav_lds_bytes, &c->big_lds_enabled_i, stream));
+                else WF_TIMED(1, launch_wf_trav(a, trav_blocks, trav_lds_mode, trav_lds_bytes, &c->big_lds_enabled, stream));
             }
             if (ts_mask) {
                 a.trav_mask = ts_mask;

@@ -92,7 +92,8 @@ struct alignas(16) DMesh {
     // 4-byte fetches from five different cache lines (incoherent rays: every fetch is a line of its own).  Same bytes, same
     // (float)b / 255 conversions, same texel index -> same values.  -1 = not available (sizes differ / fixed material).
     int32_t  tex_comb;           // index into DScene.textures of the interleaved array
-    int32_t  pad2[3];
+    int32_t  i_root;             // id of this mesh's root in the split pools (DScene.inodes / lnodes): >= 0 interior record, < 0 = ~leaf record
+    int32_t  pad2[2];
 };
 static_assert(sizeof(DMesh) % 16 == 0, "DMesh must be 16-byte sized");
 
@@ -129,6 +130,13 @@ struct DScene {
     // triangle, ordered like the node pool.  A walker that has just fetched a leaf node from LDS then needs ONE more
     // 16-byte LDS read for the triangle test — no trip to global memory inside the walk.
     const PT_CONST_AS float*     e2s;
+    // The same trees once more with interior nodes and leaves in SEPARATE pools, every link explicit (wf_trav_i: only the
+    // interior records are staged in LDS — half the bytes, so a tree that needs one 1024-thread block per CU as a whole image
+    // runs two of them).  A link is an id: >= 0 = interior record, < 0 = ~(leaf record), kIdEnd = the walk of this mesh is over.
+    //   inodes: float4 pairs {bmin.xyz, id on a miss (skip link)}{bmax.xyz, id on a hit (left child)}
+    //   lnodes: float4 triples {a.xyz, id of the next node}{e1.xyz, triangle index}{e2.xyz, 0}
+    const PT_CONST_AS float*     inodes;
+    const PT_CONST_AS float*     lnodes;
     const PT_CONST_AS DTriAttr*  triattr;
     const PT_CONST_AS DTexture*  textures;
     const PT_CONST_AS uint8_t*   texels;
@@ -218,6 +226,7 @@ constexpr int kWfPlanes = 6;
 constexpr int kWfShards = 256;
 constexpr int kCandMax = 8;          // two-stage: candidate slots per queued ray (more passing triangles -> reference walk for that mesh)
 constexpr int kTwoStageMaxMeshes = 24;   // mesh index bits in cand_hdr
+constexpr int32_t kIdEnd = (int32_t)0x80000000;   // split pools: "no further node"
 struct WfArgs {
     DScene  S;
     DCamera C;

@@ -61,6 +61,15 @@
                             // (9 scalar spills) so that eight blocks per CU really fit — 6 let the compiler take 67 VGPRs / 92 SGPRs, i.e. seven.
                             // A/B at the end of round 2, cfg2 wf_trav: 6 / 7 / 8 -> 29.2 / 29.1 / 28.1 ms (HEAD scene: unchanged)
 #endif
+#ifndef PT_TRAVI_BURST
+#define PT_TRAVI_BURST 10   // wf_trav_i (interior nodes in LDS, leaves from global memory): interior steps per vote
+#endif
+#ifndef PT_TRAVI_LEAF_W
+#define PT_TRAVI_LEAF_W 3   // wf_trav_i: a leaf step is taken when n_leaf * W > n_inner
+#endif
+#ifndef PT_TRAVI_LEAF2
+#define PT_TRAVI_LEAF2 16   // wf_trav_i: a leaf step tests a second triangle when at least this many lanes sit on a leaf again
+#endif
 #ifndef PT_MIN_WAVES
 #define PT_MIN_WAVES 4      // waves per SIMD the register allocator must leave room for (<= 128 VGPRs)
 #endif
@@ -1884,6 +1893,142 @@ __global__ __launch_bounds__(BS, (BS == 256 ? PT_TRAV_WAVES : 4)) void wf_trav(W
 #endif
 }
 
+// ---------------------------------------------------------------- wf_trav_i: the walker for trees of 64 .. 150 KB
+// Same walk, same arithmetic, same results as wf_trav; different storage.  A tree whose whole image (nodes with their leaves'
+// triangles) exceeds 64 KB forces wf_trav into ONE 1024-thread block per CU: 4 waves per SIMD, which cannot cover the latency of
+// the conflicted LDS node reads (16 waves queue behind one LDS pipe) AND the dependent VALU chain of the slab test — PMC showed the
+// LDS-busy time and the VALU-issue time of that kernel ADDING up to its duration instead of overlapping.  Here only the INTERIOR
+// nodes live in LDS (pt_device.h DScene.inodes: half the bytes, every link explicit), so two such blocks fit a CU — 8 waves per
+// SIMD — and a leaf is three 16-byte reads from the leaf pool in global memory (L2-resident: 11 of the ~96 steps of a drone ray).
+template <int BS>
+__global__ __launch_bounds__(BS, 8) void wf_trav_i(WfArgs A) {
+    const DScene& S = A.S;
+    const uint32_t n_q = A.hdr[2];
+    const uint32_t n_waves = gridDim.x * ((uint32_t)BS / 64u);
+    uint32_t chunk = 256u;                                           // as wf_trav
+    if (n_q < n_waves * 256u) chunk = max(64u, ((n_q + n_waves - 1u) / n_waves + 63u) & ~63u);
+    const bool shared_part = n_waves * chunk < n_q;
+    if (blockIdx.x * ((uint32_t)BS / 64u) * chunk >= n_q) return;
+    {
+        cf4_ptr gi = (cf4_ptr)S.inodes;
+        const int nn = (int)A.R.lds_nodes * 2;
+        for (int k = threadIdx.x; k < nn; k += BS) k1_lds[k] = gi[k];
+        __syncthreads();
+    }
+    const float4* IN = k1_lds;
+    cf4_ptr LN = (cf4_ptr)S.lnodes;
+    Bvh<false> B;                                                    // mesh ROOT boxes come from the ordinary node pool (enter_next_mesh)
+    bvh_bind(B, S, 0);
+    const float t_min = 0.001f, t_max = A.C.max_trace_dist;
+    const uint32_t cap = A.cap;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave_id = blockIdx.x * ((uint32_t)BS / 64u) + (threadIdx.x >> 6);
+    uint32_t wnext = wave_id * chunk, wend = min(wnext + chunk, n_q);
+    bool drained = false;
+    if (wnext >= n_q) { wnext = wend = 0; drained = true; }
+    uint32_t wlo = drained ? 0u : wf_shard_of(A.trav_pfx, (uint32_t)__builtin_amdgcn_readfirstlane((int)wnext));
+    bool have = false;
+    size_t pos = 0;
+    f3 o = mk3(0.0f, 0.0f, 0.0f), d = o, too = o, tod = o, tinv = o;
+    Best best; best.t = 0.0f; best.obj = -1; best.tri = -1; best.u = best.v = 0.0f;
+    int tm = 0, id = kIdEnd, tbtri = -1;                             // id: the node the lane stands on (>= 0 interior: c0, c1 hold it)
+    float tbt = 0.0f, tbu = 0.0f, tbv = 0.0f;
+    float4 c0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), c1 = c0;
+
+    // the ray has passed (or skipped, for a root that is a leaf) mesh tm's root test: stand on the first node to visit
+    auto start_mesh = [&]() {
+        const int root = S.meshes[tm].i_root;
+        id = root;
+        if (root >= 0) { id = __float_as_int(IN[2 * root + 1].w); }                  // root box passed with bound t_max: its left child
+        if (id >= 0) { c0 = IN[2 * id]; c1 = IN[2 * id + 1]; }
+        tbt = t_max; tbtri = -1; tbu = tbv = 0.0f;
+    };
+
+    while (true) {
+        // ---- refill idle lanes (as wf_trav) ----
+        unsigned long long need = __builtin_amdgcn_ballot_w64(!have);
+        const uint32_t n_idle = (uint32_t)__popcll(need);
+        if ((n_idle >= A.refill_min || n_idle == 64u) && !drained) {
+            if (wnext == wend) {
+                uint32_t base = n_q;
+                if (shared_part) {
+                    if (lane == 0) base = n_waves * chunk + atomicAdd(&A.trav_head[0], chunk);
+                    base = (uint32_t)__shfl((int)base, 0);
+                }
+                if (base >= n_q) drained = true;
+                else { wnext = base; wend = min(base + chunk, n_q); wlo = wf_shard_of(A.trav_pfx, (uint32_t)__builtin_amdgcn_readfirstlane((int)base)); }
+            }
+            const uint32_t avail = wend - wnext;
+            const uint32_t rank = (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
+            const bool take = !have && rank < avail;
+            if (take) {
+                const uint32_t vi = wnext + rank;
+                uint32_t lo = wlo;
+                while (A.trav_pfx[lo + 1] <= vi) lo++;
+                pos = A.trav_q[(size_t)lo * A.region + (vi - A.trav_pfx[lo])];
+                const float4 q0 = A.st_out[st_idx(0, pos, cap)], q1 = A.st_out[st_idx(1, pos, cap)];
+                const Hit2 hr = *st_hit(A.st_out, pos, cap);
+                o = mk3(q0.x, q0.y, q0.z); d = mk3(q0.w, q1.x, q1.y);
+                best.t = hr.t; best.obj = hr.obj; best.tri = -1; best.u = 0.0f; best.v = 0.0f;
+                tm = 0;
+                int ti, tend, ttb;
+                if (enter_next_mesh(S, B, tm, o, d, t_min, t_max, too, tod, tinv, ti, tend, ttb, A.trav_mask)) { start_mesh(); have = true; }
+            }
+            wnext += min(avail, n_idle);
+            if (wnext < wend) { const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)wnext); while (A.trav_pfx[wlo + 1] <= w) wlo++; }
+        }
+        if (__builtin_amdgcn_ballot_w64(have) == 0ull) {
+            if (drained) break;
+            continue;
+        }
+        // ---- one voted step: a burst of interior nodes, or the leaves the lanes stand on ----
+        const bool at_leaf = have & (id < 0) & (id != kIdEnd), at_inner = have & (id >= 0);
+        const int n_leaf = __popcll(__builtin_amdgcn_ballot_w64(at_leaf));
+        const int n_inner = __popcll(__builtin_amdgcn_ballot_w64(at_inner));
+        if (n_inner >= n_leaf * PT_TRAVI_LEAF_W) {
+#pragma unroll
+            for (int j = 0; j < PT_TRAVI_BURST; j++) {
+                const bool act = have & (id >= 0);
+                const bool hit = slab(mk3(c0.x, c0.y, c0.z), mk3(c1.x, c1.y, c1.z), too, tinv, t_min, tbt);      // geometry.rs:103
+                const int nxt = hit ? __float_as_int(c1.w) : __float_as_int(c0.w);
+                id = act ? nxt : id;
+                if (act & (id >= 0)) { c0 = IN[2 * id]; c1 = IN[2 * id + 1]; }
+            }
+        } else {
+            for (int k = 0; k < (PT_TRAVI_LEAF2 > 0 ? 2 : 1); k++) {
+                const bool lf = have & (id < 0) & (id != kIdEnd);
+                if (k > 0 && __popcll(__builtin_amdgcn_ballot_w64(lf)) < PT_TRAVI_LEAF2) break;
+                if (lf) {
+                    const int li = ~id;
+                    const float4 l0 = LN[3 * li], l1 = LN[3 * li + 1], l2 = LN[3 * li + 2];
+                    float t, u, v;
+                    const bool ok = tri_t(too, tod, mk3(l0.x, l0.y, l0.z), mk3(l1.x, l1.y, l1.z), mk3(l2.x, l2.y, l2.z), t_min, tbt, t, u, v);   // :97
+                    const int ltri = __float_as_int(l1.w);
+                    tbt = ok ? t : tbt; tbtri = ok ? ltri : tbtri; tbu = ok ? u : tbu; tbv = ok ? v : tbv;
+                    id = __float_as_int(l0.w);
+                    if (id >= 0) { c0 = IN[2 * id]; c1 = IN[2 * id + 1]; }
+                }
+            }
+        }
+        if (have && id == kIdEnd) {
+            // this mesh is done: StaticMesh::intersect_ray returns (geometry.rs:305-313)
+            if (tbtri >= 0) consider(best, tbt, S.meshes[tm].object_index, tbtri, tbu, tbv);
+            tm++;
+            int ti, tend, ttb;
+            if (enter_next_mesh(S, B, tm, o, d, t_min, t_max, too, tod, tinv, ti, tend, ttb, A.trav_mask)) start_mesh();
+            else {
+                if (best.tri >= 0) {
+                    Hit2 hw; hw.t = best.t; hw.obj = best.obj;
+                    *st_hit(A.st_out, pos, cap) = hw;
+                    *st_tri(A.st_out, pos, cap) = best.tri;
+                    A.st_out[st_idx(5, pos, cap)] = make_float4(best.u, best.v, 0.0f, 0.0f);
+                }
+                have = false;
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------- exact two-stage mesh traversal
 // For meshes whose file order makes the reference's index-range tree useless (obj/sphere.obj: 3800 box tests and 960
 // triangle tests per entering ray).  bvh_build.hpp states the argument; in short:
@@ -2452,6 +2597,15 @@ hipError_t launch_wf_trav(const WfArgs& a, uint32_t n_blocks, int lds_mode, size
     }
     else if (lds_mode == 2) hipLaunchKernelGGL((wf_trav<2, 256>), grid, block, lds_bytes, stream, a);
     else hipLaunchKernelGGL((wf_trav<0, 256>), grid, block, 0, stream, a);
+    return hipGetLastError();
+}
+hipError_t launch_wf_trav_i(const WfArgs& a, uint32_t n_blocks, size_t lds_bytes, bool* big_lds_enabled, hipStream_t stream) {
+    if (!*big_lds_enabled) {       // the attribute belongs to the function on the current device: kept per context
+        hipError_t e = hipFuncSetAttribute((const void*)wf_trav_i<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        *big_lds_enabled = true;
+    }
+    hipLaunchKernelGGL((wf_trav_i<1024>), dim3(n_blocks), dim3(1024), lds_bytes, stream, a);
     return hipGetLastError();
 }
 hipError_t launch_wf_trav_f(const WfArgs& a, uint32_t n_blocks, hipStream_t stream) {

@@ -1,0 +1,70 @@
+"""Every storage mode of the reference-tree walker gives the same paths: BVH in global memory (0), whole image in LDS with 256-thread
+blocks (2) or one 1024-thread block per CU (3), and wf_trav_i — interior nodes in LDS, leaves from global memory, two 1024-thread
+blocks per CU (4: what trees of 64 .. 150 KB such as obj/drone.obj take by default).  The mode is a developer knob read once in
+mi_ctx_create (MI_RT_WF_TRAV_LDS), so each mode gets a context of its own; signatures must equal the oracle's bit for bit."""
+import os
+
+import numpy as np
+import pytest
+
+from cs397raytracingsp22_amd import Context, Lambertian, StaticMesh, abi, cgmath, scenes
+
+pytestmark = pytest.mark.gpu
+
+
+def render_with_mode(mode, flat, cam, seed):
+    old = os.environ.get("MI_RT_WF_TRAV_LDS")
+    os.environ["MI_RT_WF_TRAV_LDS"] = str(mode)
+    try:
+        ctx = Context(0)
+    finally:
+        if old is None:
+            del os.environ["MI_RT_WF_TRAV_LDS"]
+        else:
+            os.environ["MI_RT_WF_TRAV_LDS"] = old
+    try:
+        ctx.upload(flat)
+        f32, _, sig, _ = ctx.render(cam, seed=seed, want_sig=True, flags=abi.MI_OPT_REFERENCE_WALK)
+        return f32, sig
+    finally:
+        ctx.close()
+
+
+def test_walker_storage_modes_agree_with_the_oracle_teapot(orc):
+    sc = scenes.config2(144, 96, 16, 10)
+    flat = sc.flatten()
+    _, _, rsig, _ = orc.OracleScene(flat).render(sc.camera, seed=4)
+    ref = None
+    for mode in (0, 2, 3, 4):
+        f32, sig = render_with_mode(mode, flat, sc.camera, 4)
+        assert int((sig != rsig).sum()) == 0, f"walker mode {mode}: paths differ from the oracle"
+        ref = f32 if ref is None else ref
+        assert np.array_equal(f32, ref), mode
+
+
+def test_walker_storage_modes_agree_several_meshes_and_a_leaf_root(orc):
+    """Teapot + cube + a one-triangle mesh (its root is a leaf: never box-tested, geometry.rs:95) + the teapot again."""
+    from test_oracle_kat import cube_mesh
+    from test_gpu_edge_cases import tiny_mesh
+    sc = scenes.config2(128, 96, 16, 8)
+    grey = Lambertian(albedo=(0.7, 0.7, 0.7))
+    sc.objects.append(StaticMesh(cube_mesh(-0.5, 0.5), grey, [None] * 5, cgmath.from_translation((-1.8, 0.5, 1.0))))
+    sc.objects.append(StaticMesh(tiny_mesh(1), grey, [None] * 5, cgmath.from_translation((1.5, 2.5, 0.5))))
+    sc.objects.append(sc.objects[-3])                                     # the teapot once more (shared StaticMesh)
+    flat = sc.flatten()
+    _, _, rsig, _ = orc.OracleScene(flat).render(sc.camera, seed=11)
+    for mode in (2, 4):
+        _, sig = render_with_mode(mode, flat, sc.camera, 11)
+        assert int((sig != rsig).sum()) == 0, f"walker mode {mode}: paths differ from the oracle"
+
+
+def test_drone_takes_the_interior_in_lds_walker_and_matches(orc, gpu_ctx):
+    """cfg4's tree (3471 nodes: 140 KB as a whole image, 55 KB of interior nodes) at a small size: default mode against mode 3."""
+    sc = scenes.config4(96, 64, 16, 6, tex_size=64)
+    flat = sc.flatten()
+    _, _, rsig, _ = orc.OracleScene(flat).render(sc.camera, seed=2)
+    gpu_ctx.upload(flat)
+    _, _, sig, _ = gpu_ctx.render(sc.camera, seed=2, want_sig=True)
+    assert int((sig != rsig).sum()) == 0
+    _, sig3 = render_with_mode(3, flat, sc.camera, 2)
+    assert np.array_equal(sig3, rsig)
