@@ -147,6 +147,7 @@ struct mi_ctx {
         uint32_t fuse_max = 0, fuse_min = 32;           // wf_main: in-launch continuation (rounds: 0 = automatic; lanes needed)
         int trav_lds = -1;                              // wf_trav LDS mode override (-1 = automatic)
         int trav_bpc = 0;                               // wf_trav blocks per CU override (0 = automatic)
+        int travf_bpc = 0;                              // wf_trav_f blocks per CU override (0 = default)
         int kernel_timing = -1;                         // per-launch HIP events: -1 = single-rank renders only
         bool global_bvh = false;                        // never stage a BVH in LDS
         bool wf_stamps = false;                         // -DPT_WF_STAMPS builds: collect wf_main phase stamps
@@ -196,7 +197,7 @@ static int ctx_init(mi_ctx* c, const hipDeviceProp_t& prop) {
     env_u("MI_RT_WF_REFILL", t.refill_min);
     env_u("MI_RT_WF_FUSE_MAX", t.fuse_max); env_u("MI_RT_WF_FUSE_MIN", t.fuse_min);
     env_i("MI_RT_WF_SPLIT", t.split); env_u("MI_RT_WF_NOWAIT_BLOCKS", t.nowait_blocks);
-    env_i("MI_RT_WF_TRAV_LDS", t.trav_lds); env_i("MI_RT_WF_TRAV_BPC", t.trav_bpc); env_i("MI_RT_WF_KERNEL_TIMING", t.kernel_timing);
+    env_i("MI_RT_WF_TRAV_LDS", t.trav_lds); env_i("MI_RT_WF_TRAV_BPC", t.trav_bpc); env_i("MI_RT_WF_TRAVF_BPC", t.travf_bpc); env_i("MI_RT_WF_KERNEL_TIMING", t.kernel_timing);
     t.global_bvh = getenv("MI_RT_GLOBAL_BVH") != nullptr;
     t.wf_stamps = getenv("MI_RT_WF_STAMPS") != nullptr;
     t.debug_mask = getenv("MI_RT_DEBUG_MASK") != nullptr;
@@ -854,6 +855,10 @@ static int wf_alloc(mi_ctx* c, WfArgs& a, uint32_t spp, uint64_t max_state_bytes
     }
     if (max_paths > (1ull << 31)) max_paths = 1ull << 31;           // 32-bit path indices
     uint64_t sb = max_paths / a.npix;
+    // the smallest batch is one sample of every (padded) pixel of this rank: a caller's budget below that cannot be honoured
+    if (sb < 1 && max_state_bytes != 0)
+        return fail(MI_ERR_INVALID, "max_state_bytes = %llu is below the pipeline's minimum for this image: one sample per pixel = %llu bytes",
+                    (unsigned long long)max_state_bytes, (unsigned long long)((uint64_t)a.npix * per_path));
     if (sb < 1) sb = 1;
     if (sb > spp) sb = spp;
     for (;;) {
@@ -1139,7 +1144,7 @@ static int render_tiles_wavefront(mi_ctx* c, const K1Args& k, const mi_camera_de
     if (trav_lds_mode == 4) trav_bpc = inode_bytes <= 78u * 1024u ? 2 : 1;
     if (c->tune.trav_bpc > 0) trav_bpc = (uint32_t)c->tune.trav_bpc;
     const uint32_t trav_blocks = (uint32_t)c->n_cus * trav_bpc;
-    const uint32_t travf_blocks = (uint32_t)c->n_cus * 6u, replay_blocks = (uint32_t)c->n_cus * 8u;
+    const uint32_t travf_blocks = (uint32_t)c->n_cus * (c->tune.travf_bpc > 0 ? (uint32_t)c->tune.travf_bpc : 6u), replay_blocks = (uint32_t)c->n_cus * 8u;
 
     // per-kernel timing: one event pair per launch, summed after the frame
     size_t ev_used = 0;

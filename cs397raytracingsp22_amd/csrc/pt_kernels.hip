@@ -1743,7 +1743,9 @@ __global__ __launch_bounds__(BS, (BS == 256 ? PT_TRAV_WAVES : 4)) void wf_trav(W
     bvh_bind(B, S, lds_nn);
     const float t_min = 0.001f, t_max = A.C.max_trace_dist;
     const uint32_t cap = A.cap;
-    const int last_node = S.n_nodes - 1;
+    // clamp of the prefetch that follows the last node of a tree: inside the LDS image when there is one (it holds the head of
+    // the node pool only: a clamp to the pool's last node would read behind the staged nodes), else inside the pool
+    const int last_node = (LDS != 0 ? (int)A.R.lds_nodes : S.n_nodes) - 1;
     const uint32_t lane = threadIdx.x & 63;
 
     // wave-uniform work cursor: a chunk [wnext, wend) of the queue

@@ -96,6 +96,9 @@ struct Texture {                                       // texture.rs:12-14
         }
         return true;
     }
+    // Untrusted input: no decoder allocates for an image of more than kMaxPixels, nor for one whose file is too short to
+    // hold it (a few header bytes must not cost gigabytes); such files return None like any undecodable file (texture.rs:22-24).
+    static constexpr size_t kMaxPixels = (size_t)1 << 27;              // 134 M pixels (16384 x 8192)
     static std::optional<Texture> decode_png(const std::vector<uint8_t>& d) {
         size_t i = 8;
         uint32_t W = 0, H = 0; int depth = 0, ctype = -1, interlace = 0;
@@ -135,6 +138,7 @@ struct Texture {                                       // texture.rs:12-14
             const size_t pw = (W > p.x0) ? (W - p.x0 + p.dx - 1) / p.dx : 0, ph = (H > p.y0) ? (H - p.y0 + p.dy - 1) / p.dy : 0;
             if (pw && ph) raw_size += ph * (1 + (pw * bits_pp + 7) / 8);
         }
+        if ((size_t)W * H > kMaxPixels || raw_size / 1032 > idat.size() + 64) return std::nullopt;     // deflate expands at most 1032 : 1
         std::vector<uint8_t> raw(raw_size);
         uLongf got = (uLongf)raw_size;
         if (uncompress(raw.data(), &got, idat.data(), (uLong)idat.size()) != Z_OK || got != raw_size) return std::nullopt;
@@ -312,6 +316,8 @@ struct Texture {                                       // texture.rs:12-14
                 H = u16(seg + 1); W = u16(seg + 3);
                 const int nc = d[seg + 5];
                 if (W <= 0 || H <= 0 || (nc != 1 && nc != 3) || len < 8 + 3 * nc) return std::nullopt;
+                // every 8x8 block costs at least one bit of entropy-coded data in a first scan: a file shorter than that is truncated
+                if ((size_t)W * H > kMaxPixels || ((size_t)W * H) / 64 / 8 > d.size()) return std::nullopt;
                 progressive = m == 0xc2; have_sof = true;
                 comp.resize((size_t)nc);
                 for (int c = 0; c < nc; c++) {
@@ -338,7 +344,7 @@ struct Texture {                                       // texture.rs:12-14
             } else if (m == 0xee && len >= 14 && !memcmp(&d[seg], "Adobe", 5)) {
                 adobe_transform = d[seg + 11];
             } else if (m == 0xda) {                                       // SOS + entropy-coded data
-                if (!have_sof) return std::nullopt;
+                if (!have_sof || len < 3) return std::nullopt;            // (len >= 3: the segment holds the component count at all)
                 const int ns = d[seg];
                 if (ns < 1 || ns > (int)comp.size() || len < 6 + 2 * ns) return std::nullopt;
                 int sc[3];
@@ -548,6 +554,8 @@ struct Texture {                                       // texture.rs:12-14
         const uint8_t* cmap = d.data() + i;
         i += cmap_bytes;
         const size_t px = (size_t)bpp / 8, n = (size_t)W * H;
+        // raw: every pixel is in the file; RLE: a packet header byte stands for at most 128 pixels
+        if (n > kMaxPixels || (!rle && d.size() - i < n * px) || (rle && n / 128 > d.size() - i)) return std::nullopt;
         std::vector<uint8_t> pix(n * px);
         if (!rle) {
             if (d.size() - i < n * px) return std::nullopt;

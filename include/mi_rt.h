@@ -189,7 +189,9 @@ typedef struct mi_render_opts {
     uint64_t max_state_bytes;   /* wavefront pipeline: upper bound on the HBM it may hold for path state, queues and
                                  * sample slots (0 = 60 % of the free HBM: a whole 1080p/256 spp frame is one 112 GB
                                  * batch).  A smaller budget means more, smaller sample batches: same image, bit for
-                                 * bit, lower throughput (256 M / 64 M / 16 M paths per batch: 161 / 187 / 257 ms on cfg2) */
+                                 * bit, lower throughput (256 M / 64 M / 16 M paths per batch: 161 / 187 / 257 ms on cfg2).
+                                 * The smallest batch is one sample of every pixel of the rank (about 220 B per pixel, 290 B
+                                 * with a two-stage mesh): a non-zero budget below that is MI_ERR_INVALID, never silently exceeded */
 } mi_render_opts;               /* 32 bytes */
 
 #define MI_OPT_NO_TILE_MASKS   1u   /* camera rays test every Scene.objects entry (no per-tile frustum masks): same image */

@@ -135,12 +135,16 @@ def test_wavefront_batching_is_exact(gpu_ctx):
     gpu_ctx.upload(flat)
     ref32, ref8, refsig, _ = gpu_ctx.render(sc.camera, seed=11, want_sig=True)
     npix = pdist.tiles_padded(160, 96, 1) * pdist.TILE_PIXELS
-    bytes_per_path = 2 * 6 * 16 + 4 + 16           # mi_rt.cpp kWfBytesPerPath: ping + pong state, queue word, sample slot
+    bytes_per_path = 2 * 6 * 16 + 2 * 4 + 16       # mi_rt.cpp kWfBytesPerPath: ping + pong state, two queue words, sample slot
     small = Context(0)
     try:
         small.upload(flat)
         f32, u8, sig, _ = small.render(sc.camera, seed=11, want_sig=True, max_state_bytes=npix * 7 * bytes_per_path)
         assert small.last_pipeline_ms()["launches"] > gpu_ctx.last_pipeline_ms()["launches"]
+        # a budget below one sample per pixel cannot be honoured: an error, not a silently larger allocation
+        with pytest.raises(abi.MiError) as ei:
+            small.render(sc.camera, seed=11, max_state_bytes=npix * bytes_per_path // 2)
+        assert ei.value.code == abi.MI_ERR_INVALID and "max_state_bytes" in str(ei.value)
     finally:
         small.close()
     assert np.array_equal(sig, refsig) and np.array_equal(f32, ref32) and np.array_equal(u8, ref8)

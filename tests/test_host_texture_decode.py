@@ -163,3 +163,63 @@ def test_jpeg_variants(decoder, tmp_path, size, kw):
     got = decode(decoder, p, tmp_path)
     assert got is not None
     assert np.array_equal(got, pil_rgb(p))
+
+
+@pytest.fixture(scope="module")
+def decoder_asan(tmp_path_factory):
+    """The same decoder built with AddressSanitizer + UBSan (CPU build: sanitizers never run on the GPU box's device code)."""
+    libasan = subprocess.run(["g++", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    if not os.path.isabs(libasan) or not os.path.exists(libasan):
+        pytest.skip("libasan not available")
+    exe = tmp_path_factory.mktemp("texasan") / "texture_decode_check_asan"
+    subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                    os.path.join(ROOT, "tests", "cpp", "texture_decode_check.cpp"), "-o", str(exe), "-lz"], check=True)
+    return str(exe)
+
+
+def jpeg_with(sof_wh=None, cut_after_sos_len=False):
+    """A small valid JPEG, then its header tampered with: SOF0 width/height overwritten, or the file cut right behind an SOS
+    segment length of 2 (the component count would be read one byte past the end)."""
+    import io
+    buf = io.BytesIO()
+    synthetic(3, 32, 32, "RGB").save(buf, format="JPEG")
+    d = bytearray(buf.getvalue())
+    if sof_wh is not None:
+        k = d.index(b"\xff\xc0")
+        d[k + 5:k + 7] = sof_wh[1].to_bytes(2, "big")
+        d[k + 7:k + 9] = sof_wh[0].to_bytes(2, "big")
+    if cut_after_sos_len:
+        k = d.index(b"\xff\xda")
+        d = d[:k + 2] + b"\x00\x02"
+    return bytes(d)
+
+
+def test_hostile_headers_are_refused_without_allocating_or_overreading(decoder_asan, tmp_path):
+    cases = {
+        "sos_cut.jpg": jpeg_with(cut_after_sos_len=True),                 # SOS of length 2 ending at EOF
+        "huge_sof.jpg": jpeg_with(sof_wh=(65535, 65535)),                 # 4.3 G pixels claimed by a 1 KB file
+        "wide_sof.jpg": jpeg_with(sof_wh=(16000, 8000)),                  # under the pixel cap, far beyond what the bytes can hold
+    }
+    # PNG: a 32768 x 32768 header over a few bytes of IDAT (CRC-correct chunks)
+    import struct
+    import zlib
+
+    def chunk(t, b):
+        return struct.pack(">I", len(b)) + t + b + struct.pack(">I", zlib.crc32(t + b) & 0xffffffff)
+    cases["huge.png"] = (b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", 32768, 32768, 8, 2, 0, 0, 0)) +
+                         chunk(b"IDAT", zlib.compress(b"\x00" * 64)) + chunk(b"IEND", b""))
+    # TGA: 65535 x 65535 true-colour, raw and RLE, 18-byte header + a few bytes
+    for name, itype in (("huge_raw.tga", 2), ("huge_rle.tga", 10)):
+        h = bytearray(18)
+        h[2] = itype
+        h[12:14] = (65535).to_bytes(2, "little")
+        h[14:16] = (65535).to_bytes(2, "little")
+        h[16] = 24
+        cases[name] = bytes(h) + b"\x7f" + b"\x01\x02\x03" * 4
+    for name, data in cases.items():
+        p = tmp_path / name
+        p.write_bytes(data)
+        out = tmp_path / "o.raw"
+        r = subprocess.run([decoder_asan, str(p), str(out)], capture_output=True, text=True,
+                           env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1:max_allocation_size_mb=512"))
+        assert r.returncode == 3, (name, r.returncode, r.stderr[-800:])   # 3 = nullopt (None); anything else is a crash or a decode
