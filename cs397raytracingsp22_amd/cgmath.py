@@ -65,15 +65,42 @@ def from_angle_z(deg):
 
 
 def mul(*ms):
+    """Matrix4 * Matrix4 with cgmath's arithmetic: column c of the product is self * rhs[c], and Matrix4 * Vector4 is
+    ((col0 * x + col1 * y) + col2 * z) + col3 * w — every operation a separate f32 rounding (Rust never fuses).  Written out
+    (not numpy's matmul, whose summation order and FMA use belong to the BLAS underneath) so that the compiled mirror
+    (host/geometry.hpp Matrix4::operator*) produces the same bits."""
     out = ms[0].astype(np.float32)
     for m in ms[1:]:
-        out = (out @ m.astype(np.float32)).astype(np.float32)
+        r = m.astype(np.float32)
+        prod = np.empty((4, 4), np.float32)
+        for c in range(4):
+            x, y, z, w = r[0, c], r[1, c], r[2, c], r[3, c]
+            prod[:, c] = ((out[:, 0] * x + out[:, 1] * y) + out[:, 2] * z) + out[:, 3] * w
+        out = prod
     return out
 
 
 def inverse_transform(m):
-    """Matrix4::inverse_transform (general inverse); computed in f64, rounded to f32."""
-    return np.linalg.inv(m.astype(np.float64)).astype(np.float32)
+    """Matrix4::inverse_transform (geometry.rs:168): the general inverse.  Gauss-Jordan with partial pivoting in f64, rounded
+    to f32 at the end — one fixed sequence of IEEE double operations, the same the compiled mirror runs
+    (host/geometry.hpp Matrix4::inverse_transform), so both mirrors hand the library the same 16 floats.  cgmath itself
+    inverts with f32 cofactors; its exact operation order is not restated here (parity unpinned)."""
+    a = [[float(m[r, c]) for c in range(4)] + [1.0 if r == c else 0.0 for c in range(4)] for r in range(4)]
+    for i in range(4):
+        p = i
+        for r in range(i + 1, 4):
+            if abs(a[r][i]) > abs(a[p][i]):
+                p = r
+        if abs(a[p][i]) < 1e-30:
+            raise np.linalg.LinAlgError("transform is not invertible")
+        a[i], a[p] = a[p], a[i]
+        d = a[i][i]
+        a[i] = [v / d for v in a[i]]
+        for r in range(4):
+            if r != i:
+                f = a[r][i]
+                a[r] = [a[r][c] - f * a[i][c] for c in range(8)]
+    return np.array([[a[r][4 + c] for c in range(4)] for r in range(4)], dtype=np.float64).astype(np.float32)
 
 
 def cols16(m):

@@ -15,5 +15,5 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-ma
 "$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$OUT/libmi_rt.so" "$OUT/pt_kernels.o" "$OUT/mi_rt.o" -ldl -lpthread
 rm -f "$OUT/pt_kernels.o" "$OUT/mi_rt.o"
 # C++ caller of the C ABI through the host mirror of the reference interface (host/*.hpp)
-g++ -std=c++17 -O2 -Wall -I"$HERE/../../include" "$HERE/../host/mi_rt_cli.cpp" -o "$OUT/mi_rt_cli" -L"$OUT" -lmi_rt -lz -Wl,-rpath,'$ORIGIN'
+g++ -std=c++17 -O2 -ffp-contract=off -Wall -I"$HERE/../../include" "$HERE/../host/mi_rt_cli.cpp" -o "$OUT/mi_rt_cli" -L"$OUT" -lmi_rt -lz -Wl,-rpath,'$ORIGIN'
 echo "built $OUT/libmi_rt.so and $OUT/mi_rt_cli"

@@ -25,27 +25,39 @@ struct Matrix4 {
     float m[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
     static Matrix4 from_translation(Vec3 v) { Matrix4 r; r.m[12] = v[0]; r.m[13] = v[1]; r.m[14] = v[2]; return r; }
     static Matrix4 from_scale(float s) { Matrix4 r; r.m[0] = r.m[5] = r.m[10] = s; return r; }
+    // Deg -> (sin, cos): radians in f64 rounded to f32, sine and cosine of THAT in f64 rounded to f32 — the definition of the
+    // Python mirror (cgmath.py _sc: math.radians, math.sin, math.cos), so both mirrors build the same matrices bit for bit
+    static void sincos_deg(float deg, float& s, float& c) {
+        const float r = (float)((double)deg * (3.14159265358979323846 / 180.0));
+        s = (float)sin((double)r); c = (float)cos((double)r);
+    }
     static Matrix4 from_angle_x(float deg) {
-        float a = deg * 3.14159265358979323846f / 180.0f, s = sinf(a), c = cosf(a);
+        float s, c; sincos_deg(deg, s, c);
         Matrix4 r; r.m[5] = c; r.m[6] = s; r.m[9] = -s; r.m[10] = c; return r;
     }
     static Matrix4 from_angle_y(float deg) {
-        float a = deg * 3.14159265358979323846f / 180.0f, s = sinf(a), c = cosf(a);
+        float s, c; sincos_deg(deg, s, c);
         Matrix4 r; r.m[0] = c; r.m[2] = -s; r.m[8] = s; r.m[10] = c; return r;
     }
     static Matrix4 from_angle_z(float deg) {
-        float a = deg * 3.14159265358979323846f / 180.0f, s = sinf(a), c = cosf(a);
+        float s, c; sincos_deg(deg, s, c);
         Matrix4 r; r.m[0] = c; r.m[1] = s; r.m[4] = -s; r.m[5] = c; return r;
     }
+    // cgmath's Matrix4 * Matrix4: column c of the product is self * rhs[c] = ((col0 * x + col1 * y) + col2 * z) + col3 * w, every
+    // operation rounded to f32 on its own (volatile-free: compiled without FMA contraction, csrc/build.sh)
     Matrix4 operator*(const Matrix4& o) const {
         Matrix4 r;
-        for (int c = 0; c < 4; c++) for (int rw = 0; rw < 4; rw++) {
-            float s = 0; for (int k = 0; k < 4; k++) s += m[k * 4 + rw] * o.m[c * 4 + k];
-            r.m[c * 4 + rw] = s;
+        for (int c = 0; c < 4; c++) {
+            const float x = o.m[c * 4 + 0], y = o.m[c * 4 + 1], z = o.m[c * 4 + 2], w = o.m[c * 4 + 3];
+            for (int rw = 0; rw < 4; rw++) {
+                const float a = m[0 * 4 + rw] * x, b = m[1 * 4 + rw] * y, cc = m[2 * 4 + rw] * z, dd = m[3 * 4 + rw] * w;
+                r.m[c * 4 + rw] = ((a + b) + cc) + dd;
+            }
         }
         return r;
     }
-    // Matrix4::inverse_transform (geometry.rs:168): general inverse (Gauss-Jordan in f64, rounded to f32)
+    // Matrix4::inverse_transform (geometry.rs:168): general inverse (Gauss-Jordan with partial pivoting in f64, rounded to f32;
+    // operation for operation what cgmath.py inverse_transform does)
     std::optional<Matrix4> inverse_transform() const {
         double a[4][8];
         for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) { a[r][c] = m[c * 4 + r]; a[r][4 + c] = r == c; }
