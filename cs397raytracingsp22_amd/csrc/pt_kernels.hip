@@ -1706,7 +1706,9 @@ template <> struct TravBvh<2> { typedef BvhNodesLds type; };
 __device__ __forceinline__ void bvh_bind(BvhNodesLds& B, const DScene& S, int) { B.nodes = k1_lds; B.tris = (cf4_ptr)S.tris; }
 
 // BS: threads per block.  256 for the small-LDS modes; 1024 (one block per CU) when the node array needs most of a
-// CU's 160 KB of LDS (meshes of ~1-2.5 k triangles: the drone's 3471 nodes = 111 KB).
+// CU's 160 KB of LDS.  (Round 3: trees of that size — the drone's 3471 nodes = 140 KB with their leaves — now take wf_trav_i below,
+// which keeps only the interior nodes in LDS and runs TWO 1024-thread blocks per CU; this form remains for trees whose interior
+// nodes alone exceed 78 KB while the whole image still fits 156 KB, and as a cross-check: tests/test_gpu_walkers.py.)
 // (Negative result, round 2: TWO RAYS PER LANE in the 1024-thread form — it runs 4 waves per SIMD whatever its register count,
 // PMC shows 43 % of a wave's life parked at s_waitcnt, so two interleaved walks per lane looked free.  Built as a template
 // parameter with the per-ray state slimmed to fit 128 VGPRs without spills (o, d re-read for a further mesh, the hit record
@@ -2114,6 +2116,10 @@ __device__ __forceinline__ bool enter_next_mesh_f(const DScene& S, int& m, uint3
 }
 
 // pass 1: persistent walkers over the traversal queue (work distribution and refill exactly as wf_trav)
+// (Negative result, round 3: the top levels of the F-trees staged in LDS — pool re-ordered to [top levels][deeper subtrees], every link
+// explicit, 2048 nodes = 64 KB per 1024-thread block — is bit-exact and changes nothing: wf_trav_f 25.1 -> 25.0 ms on the HEAD scene.  A
+// wave's step waits for its slowest lane, and some lane is always below the top levels; more resident waves do not help either
+// (4 / 6 / 8 blocks per CU: 30.0 / 24.6 / 25.2 ms): the kernel is bound by VALU issue at 33 of 64 lanes.  tools/experiments/.)
 // (Negative result, round 2: flag bits in the queue word — "enters a reference-walk mesh" / "enters a two-stage mesh", so that each
 // walker skips the entries that are not for it without touching the path state — need wf_main to test EVERY mesh root instead
 // of stopping at the first one entered: wf_main +2.5 ms on cfg2, +1.2 ms on the HEAD scene, wf_trav_f only -0.3 ms.)

@@ -4,6 +4,7 @@
     python tools/prof_json.py <outdir> <config> <tag>
 
   profiles/<tag>_<config>_kernel_stats.csv   the `--kernel-trace --stats` summary, verbatim
+  (profiles/<tag>_<config>_bench.log          is written afterwards by tools/prof_all.sh: a plain bench.py run that reads the files below)
   profiles/<tag>_<config>_pmc.json           per kernel (wf_main / wf_trav / ...): launches, ms per frame and every
                                              counter summed over one frame, plus the derived HBM and VALU figures
   profiles/traffic_<config>.json             what bench.py reads: HBM bytes per frame (FETCH_SIZE x 2 + WRITE_SIZE,
@@ -67,7 +68,19 @@ def main():
             for row in csv.DictReader(open(f)):
                 if ours(row["Kernel_Name"]):
                     kern[short(row["Kernel_Name"])]["counters"][row["Counter_Name"]] += float(row["Counter_Value"])
+    # the frame each PMC pass measured: bench.py's own JSON line in the pass log (one step = one frame, under the profiler)
+    frames = []
+    for sub in ("fetch", "write", "sq1", "sq2", "grbm"):
+        log = os.path.join(root, sub + ".log")
+        if os.path.exists(log):
+            for line in open(log, errors="ignore"):
+                if line.startswith("{"):
+                    try:
+                        frames.append(float(json.loads(line)["ms_per_step"]))
+                    except (ValueError, KeyError):
+                        pass
     out = {"config": cfg, "tag": tag, "source_hash": source_hash(), "kernels": {},
+           "frame_ms_profiled": (sum(frames) / len(frames) if frames else None), "frame_ms_per_pass": frames,
            "units": "per frame (one bench.py step); ms = average over the PMC passes (profiled runs are 2-3 % slower than plain ones)"}
     tot_f = tot_w = tot_ms = 0.0
     for k, v in sorted(kern.items()):
@@ -95,12 +108,13 @@ def main():
     json.dump(out, open(os.path.join(ROOT, "profiles", f"{tag}_{cfg}_pmc.json"), "w"), indent=1, sort_keys=True)
     for f in glob.glob(os.path.join(root, "trace", "**", "*kernel_stats.csv"), recursive=True):
         shutil.copy(f, os.path.join(ROOT, "profiles", f"{tag}_{cfg}_kernel_stats.csv"))
-    if os.path.exists(os.path.join(root, "trace.log")):
-        shutil.copy(os.path.join(root, "trace.log"), os.path.join(ROOT, "profiles", f"{tag}_{cfg}_bench.log"))
+    # (the bench log is NOT taken from the trace pass: it is written by tools/prof_all.sh AFTER this file exists, so that the
+    #  committed log shows the traffic and VALU figures of the profile committed beside it)
     main_k = {k: v for k, v in out["kernels"].items() if k.startswith("wf_")}
     traffic = {"config": cfg, "tag": tag, "source_hash": out["source_hash"],
                "kernel": "K1w pipeline: every wf_* launch of one frame",
                "hbm_bytes_per_launch": (tot_f + tot_w) or None, "fetch_bytes_corrected_x2": tot_f, "write_bytes": tot_w,
+               "frame_ms_profiled": out["frame_ms_profiled"],
                "per_kernel": {k: {"ms": v["ms"], "hbm_bytes": v.get("hbm_bytes"), "hbm_GBps": v.get("hbm_GBps"),
                                   "valu_insts": v["counters"].get("SQ_INSTS_VALU"), "valu_issue_frac": v.get("valu_issue_frac"),
                                   "active_lanes": v.get("active_lanes")} for k, v in main_k.items()},
