@@ -55,6 +55,26 @@ def random_scene(seed):
                         cgmath.from_scale(scale))
         objs.append(StaticMesh(scenes.load_asset_mesh(name), mat, tex, xf))
     objs.append(Triangle((-6, 9, -6), (6, 9, -6), (0, 9, 6), Lambertian(albedo=(0.5, 0.5, 0.5), emission=(5.0, 5.0, 5.0))))
+    # ABI 4 surface, drawn from a generator of its own (the scenes of earlier rounds keep their other objects): ConvexVolumes over
+    # a StaticMesh, a nested Scene or a lone Triangle, and the same StaticMesh listed twice (Arc sharing)
+    r2 = np.random.default_rng(seed ^ 0x5eed4)
+    fog = lambda: Isotropic(albedo=tuple(float(x) for x in r2.uniform(0.2, 1.0, 3)))      # noqa: E731
+    if r2.random() < 0.25:
+        xf = cgmath.mul(cgmath.from_translation(tuple(float(x) for x in r2.uniform(-2, 2, 3) + np.array([0, 2, -1]))),
+                        cgmath.from_angle_y(float(r2.uniform(0, 360))), cgmath.from_scale(float(r2.uniform(0.4, 1.0))))
+        objs.append(ConvexVolume(StaticMesh(scenes.load_asset_mesh("cube"), Dielectric(1.5), [None] * 5, xf), fog(), float(r2.uniform(0.5, 4.0))))
+    if r2.random() < 0.2:
+        c = r2.uniform(-2, 2, 3) + np.array([0, 2.0, -1])
+        inner = [Sphere(tuple(float(x) for x in c + r2.uniform(-0.5, 0.5, 3)), float(r2.uniform(0.4, 0.9)), Dielectric(1.5)) for _ in range(int(r2.integers(1, 4)))]
+        p3 = r2.uniform(-1.5, 1.5, (3, 3)) + c
+        inner.append(Triangle(tuple(map(float, p3[0])), tuple(map(float, p3[1])), tuple(map(float, p3[2])), Dielectric(1.5)))
+        objs.append(ConvexVolume(Scene(Camera(), inner), fog(), float(r2.uniform(0.5, 4.0))))
+    if r2.random() < 0.1:
+        p3 = r2.uniform(-3, 3, (3, 3)) + np.array([0, 2.5, -2])
+        objs.append(ConvexVolume(Triangle(tuple(map(float, p3[0])), tuple(map(float, p3[1])), tuple(map(float, p3[2])), Dielectric(1.5)), fog(), 2.0))
+    meshes = [o for o in objs if isinstance(o, StaticMesh)]
+    if meshes and r2.random() < 0.25:
+        objs.append(meshes[int(r2.integers(0, len(meshes)))])
     order = rng.permutation(len(objs))
     objs = [objs[i] for i in order]                       # Scene.objects order matters (ties, volume RNG draws)
     spp = int(rng.choice([1, 4, 9, 16]))
