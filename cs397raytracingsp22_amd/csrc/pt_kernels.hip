@@ -2119,7 +2119,8 @@ __device__ __forceinline__ bool enter_next_mesh_f(const DScene& S, int& m, uint3
 // (Negative result, round 3: the top levels of the F-trees staged in LDS — pool re-ordered to [top levels][deeper subtrees], every link
 // explicit, 2048 nodes = 64 KB per 1024-thread block — is bit-exact and changes nothing: wf_trav_f 25.1 -> 25.0 ms on the HEAD scene.  A
 // wave's step waits for its slowest lane, and some lane is always below the top levels; more resident waves do not help either
-// (4 / 6 / 8 blocks per CU: 30.0 / 24.6 / 25.2 ms): the kernel is bound by VALU issue at 33 of 64 lanes.  tools/experiments/.)
+// (4 / 6 / 8 blocks per CU: 30.0 / 24.6 / 25.2 ms) although VALU issue is only 0.34: the limit is the line traffic of the gathers (every
+// 32-byte node read moves a whole cache line from L2); a node that fills its line would cut it.  DESIGN.md section 4, tools/experiments/.)
 // (Negative result, round 2: flag bits in the queue word — "enters a reference-walk mesh" / "enters a two-stage mesh", so that each
 // walker skips the entries that are not for it without touching the path state — need wf_main to test EVERY mesh root instead
 // of stopping at the first one entered: wf_main +2.5 ms on cfg2, +1.2 ms on the HEAD scene, wf_trav_f only -0.3 ms.)
