@@ -148,3 +148,17 @@ def test_png_writer_round_trip(tmp_path):
     from PIL import Image
     back = np.asarray(Image.open(path).convert("RGB"))
     assert np.array_equal(back, img)
+
+
+def test_bench_without_a_launcher_takes_the_in_process_route_and_fails_loudly_without_gpus():
+    """`python bench.py --gpus N` (no torch.distributed.run, WORLD_SIZE unset) must go through mi_multi_* in-process — never ask for a
+    launcher, never fall back to anything: on a box without devices that is mi_multi_create's own error and a non-zero exit."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present (tests/test_gpu_multi.py covers the route there)")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0
+    assert "no CPU fallback" in r.stderr and "torch.distributed.run" not in r.stderr
+    assert not any(line.startswith("{") for line in r.stdout.splitlines())      # no result line was printed
