@@ -134,7 +134,7 @@ struct mi_ctx {
     struct MeshBox { bool cullable; double corner[8][3]; };
     std::vector<MeshBox> h_mesh_box;                 // world-space corners of every live mesh's root box
     std::vector<unsigned long long> h_tile_mask; void* d_tile_mask = nullptr; size_t tile_mask_bytes = 0;
-    mi_camera_desc mask_cam{}; bool mask_valid = false;
+    mi_camera_desc mask_cam{}; uint32_t mask_stride = 0; bool mask_valid = false;
     std::vector<hipEvent_t> wf_ev;                   // event pool for per-kernel timing of the pipeline
     float wf_ms[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };     // last frame: wf_main, wf_trav, wf_reduce totals (ms), launches, wf_trav_f, wf_replay
     int n_cus = 256;
@@ -777,8 +777,17 @@ static int check_camera(const mi_camera_desc* cam) {
     return MI_OK;
 }
 
+// The tile grid of the partition.  Tiles are numbered row-major over a grid whose ROW LENGTH `tx` is the image's tile columns
+// rounded up to the next integer coprime with `world` (tile t -> rank t % world, slot t / world): a row length that shares a factor
+// with the rank count repeats the same few column classes for a rank in every row (60 columns over 8 ranks: two classes, and the
+// ranks whose classes cross the expensive middle of the frame took 7 % longer than the others); a coprime one walks every rank
+// through all classes.  The extra columns hold no pixel: their tiles are rendered as "outside the image" (zeros) and never
+// copied anywhere.  world = 1 (mi_render) keeps the plain grid.
 static void tile_counts(const mi_camera_desc* cam, int world, uint32_t* tx, uint32_t* ty, uint32_t* total, uint32_t* padded) {
-    *tx = (cam->screen_width + MI_TILE - 1) / MI_TILE;
+    uint32_t stride = (cam->screen_width + MI_TILE - 1) / MI_TILE;
+    auto gcd = [](uint32_t a, uint32_t b) { while (b) { const uint32_t r = a % b; a = b; b = r; } return a; };
+    while (gcd(stride, (uint32_t)world) != 1u) stride++;
+    *tx = stride;
     *ty = (cam->screen_height + MI_TILE - 1) / MI_TILE;
     *total = *tx * *ty;
     *padded = (*total + (uint32_t)world - 1) / (uint32_t)world;
@@ -904,13 +913,13 @@ static int wf_prepare(mi_ctx* c, const mi_camera_desc* cam, uint32_t padded, uin
 // dropped from the tile's mask and its test — which would have missed — is not run.  f64 on the host,
 // a further 1e-4 scene-unit slack; any non-finite value or a singular camera basis keeps everything.
 // Planes and ConvexVolumes are never masked.  Returns false when masking does not apply.
-static bool tile_masks(mi_ctx* c, const mi_camera_desc* cam, uint32_t flags) {
+static bool tile_masks(mi_ctx* c, const mi_camera_desc* cam, uint32_t flags, uint32_t stride) {
     const int n_ts = c->h_n_tri + c->h_n_sphere;
     const int n_mesh = (int)c->h_mesh_box.size();
     if ((n_ts == 0 && n_mesh == 0) || n_ts > 64 || n_mesh > 32) return false;
     // rays must leave the eye itself (no lens) towards the image plane (focus_dist > 0 keeps the direction's sign)
     if (cam->projection_mode != MI_PROJ_PERSPECTIVE || cam->lens_radius != 0.0f || !(cam->focus_dist > 0.0f) || (flags & MI_OPT_NO_TILE_MASKS)) return false;
-    if (c->mask_valid && memcmp(&c->mask_cam, cam, sizeof *cam) == 0) return true;
+    if (c->mask_valid && c->mask_stride == stride && memcmp(&c->mask_cam, cam, sizeof *cam) == 0) return true;
     const double W = cam->screen_width, H = cam->screen_height, p = 1.0 / H;
     const double view[3] = { cam->view_dir[0], cam->view_dir[1], cam->view_dir[2] };
     const double up[3] = { cam->up[0], cam->up[1], cam->up[2] };
@@ -926,7 +935,8 @@ static bool tile_masks(mi_ctx* c, const mi_camera_desc* cam, uint32_t flags) {
         const double x = p * (px - 0.5 * W + 0.5), y = p * (0.5 + 0.5 * H - py), z = -(double)cam->focal_length;
         for (int k = 0; k < 3; k++) o[k] = c0[k] * x + up[k] * y + -view[k] * z;
     };
-    const uint32_t tx = (cam->screen_width + MI_TILE - 1) / MI_TILE, ty = (cam->screen_height + MI_TILE - 1) / MI_TILE;
+    // `stride` >= the image's tile columns: the row length of the tile numbering (tile_counts); the surplus columns hold no pixel
+    const uint32_t tx = stride, tx_image = (cam->screen_width + MI_TILE - 1) / MI_TILE, ty = (cam->screen_height + MI_TILE - 1) / MI_TILE;
     // [0, tiles): list masks; [tiles, 2*tiles): low 32 bits = mesh mask, bit 63 = DEAD tile (nothing reachable:
     // every camera ray of the tile leaves the scene at once)
     const size_t n_tiles = (size_t)tx * ty;
@@ -988,6 +998,10 @@ static bool tile_masks(mi_ctx* c, const mi_camera_desc* cam, uint32_t flags) {
         }
     }
     for (uint32_t j = 0; j < ty; j++) for (uint32_t i = 0; i < tx; i++) {
+        if (i >= tx_image) {                     // a column beyond the image: nothing to render, whatever the scene holds
+            c->h_tile_mask[(size_t)j * tx + i] = 0ull; c->h_tile_mask[n_tiles + (size_t)j * tx + i] = 1ull << 63;
+            continue;
+        }
         const double x0 = (double)i * MI_TILE - margin_px, x1 = std::min<double>(W, (i + 1.0) * MI_TILE) - 1.0 + margin_px;
         const double y0 = (double)j * MI_TILE - margin_px, y1 = std::min<double>(H, (j + 1.0) * MI_TILE) - 1.0 + margin_px;
         double cs[4][3], ctr[3], n[4][3];
@@ -1047,7 +1061,7 @@ static bool tile_masks(mi_ctx* c, const mi_camera_desc* cam, uint32_t flags) {
         if ((mask & ts_bits) == 0ull && (mm & mesh_bits) == 0ull && c->h_n_unmasked == 0 && n_mesh <= 32) mm |= 1ull << 63;
         c->h_tile_mask[n_tiles + (size_t)j * tx + i] = mm;
     }
-    c->mask_cam = *cam; c->mask_valid = false;              // valid once uploaded
+    c->mask_cam = *cam; c->mask_stride = stride; c->mask_valid = false;              // valid once uploaded
     if (c->tune.debug_mask) {
         size_t bits = 0, mbits = 0, dead = 0;
         for (size_t t = 0; t < n_tiles; t++) {
@@ -1086,7 +1100,7 @@ static int render_tiles_wavefront(mi_ctx* c, const K1Args& k, const mi_camera_de
     a.trav_q = (uint32_t*)c->d_wf_q; a.samp = (float4*)c->d_wf_samp; a.accum = range.accum ? range.accum : (float4*)c->d_wf_acc;
     a.out = d_compact; a.sig = d_sig;
     a.tile_mask = nullptr;
-    if (tile_masks(c, cam, flags)) {
+    if (tile_masks(c, cam, flags, a.R.tiles_x)) {
         if (!c->mask_valid) {
             int rcm = ensure(&c->d_tile_mask, &c->tile_mask_bytes, c->h_tile_mask.size() * sizeof(unsigned long long));
             if (rcm != MI_OK) return rcm;
@@ -1379,6 +1393,7 @@ static int render_tiles(mi_ctx* c, const mi_camera_desc* cam, const mi_render_op
         uint64_t pixels = 0;
         for (uint32_t t = (uint32_t)o->rank; t < total; t += (uint32_t)o->world) {
             uint32_t x0 = (t % tx) * MI_TILE, y0 = (t / tx) * MI_TILE;
+            if (x0 >= cam->screen_width) continue;               // a column of the numbering beyond the image (tile_counts)
             uint32_t w = cam->screen_width - x0 < MI_TILE ? cam->screen_width - x0 : MI_TILE;
             uint32_t h = cam->screen_height - y0 < MI_TILE ? cam->screen_height - y0 : MI_TILE;
             pixels += (uint64_t)w * h;

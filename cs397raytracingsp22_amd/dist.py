@@ -1,6 +1,7 @@
 """One process per GPU: image tiles sharded over ranks, one gather per frame.
 
-Partition: the image is cut into 32x32-pixel tiles, numbered row-major;
+Partition: the image is cut into 32x32-pixel tiles, numbered row-major over a
+grid whose row length is coprime with the rank count (tile_grid);
 tile t belongs to rank t % world and lands in slot t // world of that rank's compact
 buffer [tiles_padded][1024][3] f32.  Interleaving spreads the expensive region (teapot,
 glass) over all ranks.  The RNG is keyed by the GLOBAL pixel index, so the assembled
@@ -22,26 +23,32 @@ TILE = abi.MI_TILE
 TILE_PIXELS = TILE * TILE
 
 
-def tile_grid(width: int, height: int):
+def tile_grid(width: int, height: int, world: int = 1):
+    """(row length, rows, tiles) of the partition's tile numbering.  The row length is the image's tile columns rounded up to the
+    next integer coprime with `world` (mi_rt.cpp tile_counts): a rank then walks through every column class instead of the same
+    few in every row.  The surplus columns hold no pixel."""
+    import math
     tx = (width + TILE - 1) // TILE
+    while math.gcd(tx, world) != 1:
+        tx += 1
     ty = (height + TILE - 1) // TILE
     return tx, ty, tx * ty
 
 
 def tiles_padded(width: int, height: int, world: int) -> int:
-    _, _, total = tile_grid(width, height)
+    _, _, total = tile_grid(width, height, world)
     return (total + world - 1) // world
 
 
 def tiles_of_rank(width: int, height: int, rank: int, world: int):
-    _, _, total = tile_grid(width, height)
+    _, _, total = tile_grid(width, height, world)
     return list(range(rank, total, world))
 
 
 def compact_index(width: int, height: int, world: int):
     """For every pixel (y, x): (rank, flat index into that rank's [tiles_padded*1024] buffer).
     Pure arithmetic mirror of K3's mapping (csrc/pt_kernels.hip fb_unpermute)."""
-    tx, _, _ = tile_grid(width, height)
+    tx, _, _ = tile_grid(width, height, world)
     y, x = np.mgrid[0:height, 0:width]
     tile = (y // TILE) * tx + (x // TILE)
     rank = tile % world

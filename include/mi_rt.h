@@ -247,7 +247,9 @@ int  mi_render(mi_ctx* ctx, const mi_camera_desc* cam, const mi_render_opts* opt
  * iterations from the host and synchronises `stream` inside mi_render_tiles_device.
  *
  * mi_render_tiles_device: rank `opts->rank` of `opts->world` renders its tiles
- *   (tile t -> rank t % world, slot t / world) into a compact tile-major buffer
+ *   (tile t -> rank t % world, slot t / world; tiles are numbered row-major over a grid whose row length is the image's tile
+ *   columns rounded up to the next integer coprime with `world`, so that every rank meets every column class — the surplus
+ *   columns hold no pixel and are written as zeros; mi_compact_size gives the counts) into a compact tile-major buffer
  *   d_compact[tiles_padded][MI_TILE*MI_TILE][3] f32 (row-major inside a tile; pixels
  *   outside the image are written as 0).  d_sig (may be NULL) is [tiles_padded][MI_TILE*MI_TILE] u32.
  * mi_unpermute_device: gathered buffer [world][tiles_padded][1024][3] -> row-major W*H*3 f32.

@@ -47,7 +47,8 @@ def test_compact_size_matches_host_arithmetic(gpu_ctx):
     sc = scenes.config2(1920, 1080, 4)
     for world in (1, 2, 4, 8):
         total, padded = compact_size(sc.camera, world)
-        assert total == 60 * 34 and padded == pdist.tiles_padded(1920, 1080, world)
+        # 60 tile columns; the numbering's row length is the next integer coprime with the rank count (61 for 2, 4, 8 ranks)
+        assert total == (60 if world == 1 else 61) * 34 and padded == pdist.tiles_padded(1920, 1080, world)
 
 
 def test_full_size_properties(gpu_ctx, orc):

@@ -86,7 +86,10 @@ def test_tile_partition_arithmetic():
     W, H = 75, 41                                                # ragged: 3 x 2 tiles
     tx, ty, total = dist.tile_grid(W, H)
     assert (tx, ty, total) == (3, 2, 6)
-    for world in (1, 2, 4, 5, 8):
+    # the row length of the numbering is coprime with the rank count: 3 columns stay 3 for 2 / 4 / 8 ranks, become 4 for 3 ranks
+    assert dist.tile_grid(W, H, 8)[0] == 3 and dist.tile_grid(W, H, 3)[0] == 4 and dist.tile_grid(1920, 1080, 8)[0] == 61
+    for world in (1, 2, 3, 4, 5, 8):
+        tx, ty, total = dist.tile_grid(W, H, world)
         padded = dist.tiles_padded(W, H, world)
         owned = [dist.tiles_of_rank(W, H, r, world) for r in range(world)]
         assert sorted(sum(owned, [])) == list(range(total))      # a partition
