@@ -38,6 +38,10 @@
 #ifndef PT_MAIN_WAVES
 #define PT_MAIN_WAVES 6     // wf_main: waves per SIMD the register allocator must allow (A/B round 2: 4 -> 90 VGPRs 99.5 ms, 6 -> 80 VGPRs 97.4 ms on cfg2)
 #endif
+#ifndef PT_MAIN_WAVES_LEAN
+#define PT_MAIN_WAVES_LEAN 7  // wf_main without the mesh branch (camera-ray pass, class-A parts, scenes without meshes): 60 VGPRs, no scratch, no
+                              // scalar spills (the full form: 80 / 12 B / 16).  6 / 7 / 8: cfg2 82.9 / 82.8 / 83.0 ms, cfg1 41.3 / 40.8 / 41.0
+#endif
 #ifndef PT_TRAV_BURST
 #define PT_TRAV_BURST 10    // wf_trav / wf_trav_f: interior steps per vote.  Round 1 (triangles fetched from global memory in the leaf
                             // step): 2/4/6/8 -> 52.6/46.8/45.8/46.3 ms.  Round 2 (leaves in the LDS image): 6/8/10/12/16 -> 30.7/29.6/28.6/29.4/31.0 ms
@@ -513,10 +517,13 @@ __device__ __forceinline__ void face(f3 normal, f3 dir, f3& n_out, bool& frontfa
 
 // Build the hit record of the winning object (the reference builds one per candidate
 // and keeps the closest; only the winner's is observable).
+// MESH = false compiles the mesh branch out: for launches whose pending hits cannot be mesh hits (wf_main's camera-ray pass and
+// its class-A parts: a mesh hit only ever comes back from a walker, into class B)
+template <bool MESH = true>
 __device__ __forceinline__ void resolve_hit(const DScene& S, const Best& b, f3 o, f3 d, Surf& s) {
     auto ob = &S.objects[b.obj];
     int kind = ob->kind;
-    if (kind == OBJ_MESH) {
+    if (MESH && kind == OBJ_MESH) {
         auto M = &S.meshes[ob->ref];
         // geometry.rs:304 — object-space ray (direction NOT renormalised)
         f3 oo = xform_point(M->inv_transform, o);
@@ -691,7 +698,8 @@ __device__ __forceinline__ void consider_list(Best& b, bool& have, bool ok, floa
     b.obj = take ? obj : b.obj;
     b.tri = take ? tag : b.tri;
 }
-template <bool GV = true>
+// RARE = false compiles the Plane / ConvexVolume loop out (a scene without either: the Cornell configurations)
+template <bool GV = true, bool RARE = true>
 __device__ __forceinline__ void intersect_list(const DScene& S, f3 o, f3 d, float t_min, float t_max, Rng& rng, Best& best) {
     auto L = S.list;
     int k = 0;
@@ -724,7 +732,7 @@ __device__ __forceinline__ void intersect_list(const DScene& S, f3 o, f3 d, floa
             consider_list(best, have, ok, t, ob->index, -2);
         }
     }
-    {   // Plane (geometry.rs:474-489) and ConvexVolume (geometry.rs:502-526): rare kinds, generic code
+    if (RARE) {   // Plane (geometry.rs:474-489) and ConvexVolume (geometry.rs:502-526): rare kinds, generic code
         const int end = k + S.n_list_plane + S.n_list_volume;
         for (; k < end; k++) {
             auto ob = &L[k];
@@ -737,7 +745,7 @@ __device__ __forceinline__ void intersect_list(const DScene& S, f3 o, f3 d, floa
 // ray of that tile (host-side conservative frustum test, mi_rt.cpp tile_masks), so skipping them
 // skips tests that would have missed.  `mask` is wave-uniform (SGPRs); planes and volumes are never
 // masked (a volume draws its random number for the whole ray LINE, geometry.rs:505).
-template <bool GV = true>
+template <bool GV = true, bool RARE = true>
 __device__ __forceinline__ void intersect_list_masked(const DScene& S, unsigned long long mask, f3 o, f3 d,
                                                       float t_min, float t_max, Rng& rng, Best& best) {
     auto L = S.list;
@@ -758,7 +766,7 @@ __device__ __forceinline__ void intersect_list_masked(const DScene& S, unsigned 
             consider_list(best, have, ok, t, r0->index, -2);
         }
     }
-    const int end = n_ts + S.n_list_plane + S.n_list_volume;
+    const int end = RARE ? n_ts + S.n_list_plane + S.n_list_volume : n_ts;
     for (int k = n_ts; k < end; k++) {
         auto ob = &L[k];
         test_object<GV>(S, ob, ob->index, o, d, t_min, t_max, rng, best);
@@ -1463,8 +1471,11 @@ __device__ __forceinline__ void wf_pixel_of(const WfArgs& A, uint32_t pix, uint3
     }
 }
 
-template <bool LDS, bool SIG, bool GV>
-__global__ __launch_bounds__(kBlock, PT_MAIN_WAVES) void wf_main(WfArgs A) {
+// MESH = false: the lean form for launches that cannot meet a mesh hit (iteration 0 and the class-A part of a later pass)
+// RARE = false: the scene holds no Plane and no ConvexVolume (their loop and the free-flight code are compiled out)
+// ITER0 = true: the camera-ray pass (Camera::generate_rays instead of a state load; always the lean form)
+template <bool LDS, bool SIG, bool GV, bool MESH, bool RARE, bool ITER0>
+__global__ __launch_bounds__(kBlock, (MESH ? PT_MAIN_WAVES : PT_MAIN_WAVES_LEAN)) void wf_main(WfArgs A) {
     const DScene& S = A.S;
     const DCamera& C = A.C;
     Bvh<LDS> B;            // only the mesh ROOT nodes are read here
@@ -1475,7 +1486,7 @@ __global__ __launch_bounds__(kBlock, PT_MAIN_WAVES) void wf_main(WfArgs A) {
     // beside the walkers of the previous pass, class-B blocks behind them) and on a grid that is only an upper bound of the part
     // (the host did not wait for the previous pass' header): the device-side block table says where the part really ends.
     uint32_t bid = blockIdx.x;
-    if (!A.iter0) {
+    if (!ITER0) {
         const uint32_t blocks_a = A.in_blkpfx[kWfShards], blocks_all = A.in_blkpfx[2 * kWfShards];
         if (A.part == 2u) bid += blocks_a;
         if (bid >= (A.part == 1u ? blocks_a : blocks_all)) return;
@@ -1495,12 +1506,12 @@ __global__ __launch_bounds__(kBlock, PT_MAIN_WAVES) void wf_main(WfArgs A) {
     // camera rays: what can this block's tile reach at all?  (all 256 paths of a block belong to one tile:
     // 1024 | npix, 256 | 1024, so both words are wave-uniform and stay in SGPRs)
     unsigned long long list_mask = ~0ull, mesh_word = 0xffffffffull;
-    if (A.iter0 && A.tile_mask) {
+    if (ITER0 && A.tile_mask) {
         const uint32_t slot0 = ((bid * kBlock) % A.npix) / kTilePixels;
         const uint32_t tile0 = slot0 * (uint32_t)A.R.world + (uint32_t)A.R.rank;
         if (tile0 < A.R.tiles_total) { list_mask = A.tile_mask[tile0]; mesh_word = A.tile_mask[A.R.tiles_total + tile0]; }
     }
-    if (A.iter0) {
+    if (ITER0) {
         // ---- Camera::generate_rays (tracing.rs:159-209) ----
         const uint32_t i = bid * kBlock + threadIdx.x;
         const bool valid = i < A.n_in;
@@ -1571,7 +1582,7 @@ __global__ __launch_bounds__(kBlock, PT_MAIN_WAVES) void wf_main(WfArgs A) {
         P.sig = 0;
         if (SIG) P.sig = *st_sig(A.st_in, k, cap);
         best.t = hr.t; best.obj = hr.obj; best.tri = hr_tri; best.u = 0.0f; best.v = 0.0f;
-        if (valid && best.tri >= 0) {       // plane 5 (barycentrics) exists only for mesh hits
+        if (MESH && valid && best.tri >= 0) {       // plane 5 (barycentrics) exists only for mesh hits
             const float4 q5 = A.st_in[st_idx(5, k, cap)];
             best.u = q5.x; best.v = q5.y;
         }
@@ -1585,12 +1596,12 @@ __global__ __launch_bounds__(kBlock, PT_MAIN_WAVES) void wf_main(WfArgs A) {
     // block look-up, state loads and stores.  The wave votes: it goes on only while at least `fuse_min` of its lanes
     // would continue (the others — ended, or waiting for a mesh walk — sit the extra trips out), at most `fuse_max`
     // times.  Per path the order of evaluation is untouched: same shading, same intersection, same RNG stream.
-    bool pending = (A.iter0 == 0u) && alive;            // a hit record was loaded: Scene::shade_ray, one level (tracing.rs:305-321)
-    bool need = (A.iter0 != 0u) && alive;               // a fresh ray needs Scene::intersect_ray
+    bool pending = (!ITER0) && alive;            // a hit record was loaded: Scene::shade_ray, one level (tracing.rs:305-321)
+    bool need = (ITER0) && alive;               // a fresh ray needs Scene::intersect_ray
     bool first = true, enters = false;
     int tm = 0;
     uint32_t fuse_left = A.fuse_max;
-    if (A.iter0) { best.obj = -1; best.t = 0.0f; best.tri = -1; best.u = best.v = 0.0f; }
+    if (ITER0) { best.obj = -1; best.t = 0.0f; best.tri = -1; best.u = best.v = 0.0f; }
     for (;;) {
         if (pending) {
             bool end_path;
@@ -1600,7 +1611,7 @@ __global__ __launch_bounds__(kBlock, PT_MAIN_WAVES) void wf_main(WfArgs A) {
             } else {
                 if (SIG) P.sig = sig_hit(P.sig, best.t, best.obj);
                 Surf s;
-                resolve_hit(S, best, P.o, P.d, s);
+                resolve_hit<MESH>(S, best, P.o, P.d, s);
                 P.L = mk3(P.L.x + P.T.x * s.emission.x, P.L.y + P.T.y * s.emission.y, P.L.z + P.T.z * s.emission.z);
                 P.depth++;
                 if (P.depth >= C.path_depth) {
@@ -1625,8 +1636,8 @@ __global__ __launch_bounds__(kBlock, PT_MAIN_WAVES) void wf_main(WfArgs A) {
         if (need) {
             tm = 0; enters = false;
             best.obj = -1; best.t = 0.0f; best.tri = -1; best.u = best.v = 0.0f;
-            if (first && A.iter0 && A.tile_mask) intersect_list_masked<GV>(S, list_mask, P.o, P.d, t_min, t_max, P.rng, best);
-            else intersect_list<GV>(S, P.o, P.d, t_min, t_max, P.rng, best);
+            if (first && ITER0 && A.tile_mask) intersect_list_masked<GV, RARE>(S, list_mask, P.o, P.d, t_min, t_max, P.rng, best);
+            else intersect_list<GV, RARE>(S, P.o, P.d, t_min, t_max, P.rng, best);
             f3 oo, od, inv; int ti, tend, ttb;
             enters = enter_next_mesh(S, B, tm, P.o, P.d, t_min, t_max, oo, od, inv, ti, tend, ttb, first ? (uint32_t)mesh_word : 0xffffffffu);
             // A ray that hits no object and enters no mesh ends its path at the next shade_ray level
@@ -1684,7 +1695,7 @@ __global__ __launch_bounds__(kBlock, PT_MAIN_WAVES) void wf_main(WfArgs A) {
 #ifdef PT_WF_STAMPS
     WF_STAMP(6);       // waits for the state stores too
     if (A.diag && (bid & 63u) == 0u && threadIdx.x == 0) {
-        unsigned long long* d = A.diag + (A.iter0 ? 8 : 0);
+        unsigned long long* d = A.diag + (ITER0 ? 8 : 0);
         for (int k = 0; k < 6; k++) if (stamp[k + 1] && stamp[k]) atomicAdd(&d[k], stamp[k + 1] - stamp[k]);
         atomicAdd(&d[6], 1ull);
         atomicAdd(&d[7], stamp[6] - stamp[0]);
@@ -2583,13 +2594,24 @@ hipError_t launch_branch(const K1Args& a, uint32_t n_blocks, uint32_t path_sampl
 }
 hipError_t launch_wf_main(const WfArgs& a, uint32_t n_blocks, bool sig, bool gv, hipStream_t stream) {
     dim3 grid(n_blocks), block(kBlock);
-    if (gv) {           // the scene holds a ConvexVolume whose boundary is not the inline sphere
-        if (sig) hipLaunchKernelGGL((wf_main<false, true, true>), grid, block, 0, stream, a);
-        else hipLaunchKernelGGL((wf_main<false, false, true>), grid, block, 0, stream, a);
+    // gv: the scene holds a ConvexVolume whose boundary is not the inline sphere.  The lean form (no mesh branch) serves the launches
+    // that cannot meet a mesh hit: the camera-ray pass, the class-A part of a later pass, every pass of a scene without meshes.
+    const bool lean = a.iter0 != 0u || a.part == 1u || a.S.n_meshes == 0;
+#define PT_WF_MAIN2(G, V, M, R, I) hipLaunchKernelGGL((wf_main<false, G, V, M, R, I>), grid, block, 0, stream, a)
+#define PT_WF_MAIN(G, V, M, R) do { if (a.iter0) PT_WF_MAIN2(G, V, false, R, true); else PT_WF_MAIN2(G, V, M, R, false); } while (0)
+    const bool rare = a.S.n_list_plane + a.S.n_list_volume > 0;          // (gv implies rare: it is a kind of ConvexVolume)
+    if (!rare) {
+        if (lean) { if (sig) PT_WF_MAIN(true, false, false, false); else PT_WF_MAIN(false, false, false, false); }
+        else      { if (sig) PT_WF_MAIN(true, false, true, false); else PT_WF_MAIN(false, false, true, false); }
+    } else if (lean) {
+        if (gv) { if (sig) PT_WF_MAIN(true, true, false, true); else PT_WF_MAIN(false, true, false, true); }
+        else    { if (sig) PT_WF_MAIN(true, false, false, true); else PT_WF_MAIN(false, false, false, true); }
     } else {
-        if (sig) hipLaunchKernelGGL((wf_main<false, true, false>), grid, block, 0, stream, a);
-        else hipLaunchKernelGGL((wf_main<false, false, false>), grid, block, 0, stream, a);
+        if (gv) { if (sig) PT_WF_MAIN(true, true, true, true); else PT_WF_MAIN(false, true, true, true); }
+        else    { if (sig) PT_WF_MAIN(true, false, true, true); else PT_WF_MAIN(false, false, true, true); }
     }
+#undef PT_WF_MAIN2
+#undef PT_WF_MAIN
     return hipGetLastError();
 }
 // big_lds_enabled: the calling context's record of the > 64 KB dynamic-LDS opt-in.  The attribute belongs to the
