@@ -36,7 +36,7 @@ namespace pt {
 hipError_t launch_megakernel(const K1Args& args, uint32_t n_blocks, bool lds, bool sig, size_t lds_bytes, hipStream_t stream);
 hipError_t launch_megakernel_voted(const K1Args& args, uint32_t n_blocks, bool lds, bool sig, bool diag, bool gv,
                                    size_t lds_bytes, hipStream_t stream);
-hipError_t launch_wf_main(const WfArgs& a, uint32_t n_blocks, bool sig, bool gv, hipStream_t stream);
+hipError_t launch_wf_main(const WfArgs& a, uint32_t n_blocks, bool sig, bool gv, bool tex, hipStream_t stream);
 hipError_t launch_phong(const K1Args& a, uint32_t n_blocks, bool sig, hipStream_t stream);
 hipError_t launch_branch(const K1Args& a, uint32_t n_blocks, uint32_t path_samples, bool sig, hipStream_t stream);
 hipError_t launch_wf_trav(const WfArgs& a, uint32_t n_blocks, int lds_mode, size_t lds_bytes, bool* big_lds_enabled, hipStream_t stream);
@@ -99,6 +99,7 @@ struct mi_ctx {
     void* blob = nullptr; size_t blob_bytes = 0;
     DScene S{};
     bool have_scene = false;
+    bool mesh_maps = false;                  // some mesh takes its material from maps or has a normal map: wf_main's MESH = 2 form
     bool gen_volumes = false;                // a ConvexVolume whose boundary is not the inline sphere: the kernels' GV forms
     uint32_t lds_bytes = 0;                  // bytes needed to stage nodes + tris, 0 = no meshes
     // per live mesh (Scene.objects order): end of its nodes in the node pool, does the two-stage bound apply to it at all,
@@ -718,6 +719,8 @@ extern "C" int mi_scene_upload(mi_ctx* c, const mi_scene_desc* d) {
     c->S.list = (const DObject*)(b + off_list);
     c->S.bobjs = (const DObject*)(b + off_bobj);
     c->gen_volumes = !bobjs.empty();
+    c->mesh_maps = false;
+    for (const DMesh& M : live) if (M.material < 0 || M.tex[4] >= 0) c->mesh_maps = true;
     c->h_list = list; c->h_n_tri = n_list[0]; c->h_n_sphere = n_list[1]; c->h_n_unmasked = n_list[2] + n_list[3]; c->mask_valid = false;
     c->S.n_list_tri = n_list[0]; c->S.n_list_sphere = n_list[1]; c->S.n_list_plane = n_list[2]; c->S.n_list_volume = n_list[3];
     c->S.materials = (const DMaterial*)(b + off_mat);
@@ -1267,14 +1270,14 @@ static int render_tiles_wavefront(mi_ctx* c, const K1Args& k, const mi_camera_de
             if (split) {
                 HIP_TRY(hipStreamWaitEvent(c->aux_stream, c->ev_pfx, 0));
                 a.part = 1;
-                WF_TIMED_ON(5, c->aux_stream, launch_wf_main(a, grid_a, d_sig != nullptr, c->gen_volumes, c->aux_stream));     // kind 5: its span includes waiting for CUs
+                WF_TIMED_ON(5, c->aux_stream, launch_wf_main(a, grid_a, d_sig != nullptr, c->gen_volumes, c->mesh_maps, c->aux_stream));     // kind 5: its span includes waiting for CUs
                 HIP_TRY(hipEventRecord(c->ev_part, c->aux_stream));
                 a.part = 2;
-                WF_TIMED(0, launch_wf_main(a, exact ? grid_all - grid_a : grid_all, d_sig != nullptr, c->gen_volumes, stream));
+                WF_TIMED(0, launch_wf_main(a, exact ? grid_all - grid_a : grid_all, d_sig != nullptr, c->gen_volumes, c->mesh_maps, stream));
                 HIP_TRY(hipStreamWaitEvent(stream, c->ev_part, 0));
             } else {
                 a.part = 0;
-                WF_TIMED(0, launch_wf_main(a, grid_all, d_sig != nullptr, c->gen_volumes, stream));
+                WF_TIMED(0, launch_wf_main(a, grid_all, d_sig != nullptr, c->gen_volumes, c->mesh_maps, stream));
             }
             // device-side bookkeeping: tables for the next pass and for wf_trav, and the header the host needs (grid of the
             // next pass, anything alive?), which wf_prefix stores straight into pinned host memory: the compute stream never

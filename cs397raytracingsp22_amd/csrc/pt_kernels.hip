@@ -517,9 +517,10 @@ __device__ __forceinline__ void face(f3 normal, f3 dir, f3& n_out, bool& frontfa
 
 // Build the hit record of the winning object (the reference builds one per candidate
 // and keeps the closest; only the winner's is observable).
-// MESH = false compiles the mesh branch out: for launches whose pending hits cannot be mesh hits (wf_main's camera-ray pass and
-// its class-A parts: a mesh hit only ever comes back from a walker, into class B)
-template <bool MESH = true>
+// MESH = 0 compiles the mesh branch out: for launches whose pending hits cannot be mesh hits (wf_main's camera-ray pass and
+// its class-A parts: a mesh hit only ever comes back from a walker, into class B).  MESH = 1: every mesh of the scene has a fixed
+// material and no normal map (cfg2's teapot), so texel fetches, the material-from-maps branch and the TBN are compiled out.  2: all.
+template <int MESH = 2>
 __device__ __forceinline__ void resolve_hit(const DScene& S, const Best& b, f3 o, f3 d, Surf& s) {
     auto ob = &S.objects[b.obj];
     int kind = ob->kind;
@@ -539,7 +540,7 @@ __device__ __forceinline__ void resolve_hit(const DScene& S, const Best& b, f3 o
         float tv = (u * A->tb[1] + v * A->tc[1]) + w * A->ta[1];
         // all maps of this mesh in ONE 16-byte texel (DMesh.tex_comb): fetched once, unpacked where texture.rs:26-32 is applied
         uint4 comb = make_uint4(0u, 0u, 0u, 0u);
-        const bool have_comb = M->tex_comb >= 0;
+        const bool have_comb = MESH == 2 && M->tex_comb >= 0;
         if (have_comb) {
             const uint32_t t_offset = S.textures[M->tex_comb].offset;
             const uint32_t W = (uint32_t)S.textures[M->tex_comb].width, H = (uint32_t)S.textures[M->tex_comb].height;
@@ -550,7 +551,7 @@ __device__ __forceinline__ void resolve_hit(const DScene& S, const Best& b, f3 o
             comb = ((const PT_CONST_AS uint4*)(S.texels + t_offset))[(size_t)y * W + x];
         }
         auto unpack3 = [](uint32_t px) { return mk3((float)(px & 0xffu) / 255.0f, (float)((px >> 8) & 0xffu) / 255.0f, (float)((px >> 16) & 0xffu) / 255.0f); };
-        if (M->tex[4] >= 0) {                                            // geometry.rs:276-283
+        if (MESH == 2 && M->tex[4] >= 0) {                               // geometry.rs:276-283
             f3 tan_approx = ld3(A->tan);
             f3 bitangent = normalize(cross(n, tan_approx));              // :360
             f3 tangent = normalize(cross(bitangent, n));                 // :361
@@ -562,7 +563,7 @@ __device__ __forceinline__ void resolve_hit(const DScene& S, const Best& b, f3 o
         s.p = xform_point(M->transform, hp_obj);                         // :307
         s.n = normalize(xform_vector_transposed(M->inv_transform, n));   // :297
         s.frontface = ff;
-        if (M->material >= 0) {
+        if (MESH != 2 || M->material >= 0) {
             load_material(S, M->material, s);                            // :255-256
         } else {                                                         // :259-269
             s.kind = MAT_PARAMETERIZED;
@@ -1474,7 +1475,7 @@ __device__ __forceinline__ void wf_pixel_of(const WfArgs& A, uint32_t pix, uint3
 // MESH = false: the lean form for launches that cannot meet a mesh hit (iteration 0 and the class-A part of a later pass)
 // RARE = false: the scene holds no Plane and no ConvexVolume (their loop and the free-flight code are compiled out)
 // ITER0 = true: the camera-ray pass (Camera::generate_rays instead of a state load; always the lean form)
-template <bool LDS, bool SIG, bool GV, bool MESH, bool RARE, bool ITER0>
+template <bool LDS, bool SIG, bool GV, int MESH, bool RARE, bool ITER0>
 __global__ __launch_bounds__(kBlock, (MESH ? PT_MAIN_WAVES : PT_MAIN_WAVES_LEAN)) void wf_main(WfArgs A) {
     const DScene& S = A.S;
     const DCamera& C = A.C;
@@ -2592,26 +2593,23 @@ hipError_t launch_branch(const K1Args& a, uint32_t n_blocks, uint32_t path_sampl
     else hipLaunchKernelGGL((pt_branch<false>), grid, block, 0, stream, a, path_samples);
     return hipGetLastError();
 }
-hipError_t launch_wf_main(const WfArgs& a, uint32_t n_blocks, bool sig, bool gv, hipStream_t stream) {
+hipError_t launch_wf_main(const WfArgs& a, uint32_t n_blocks, bool sig, bool gv, bool tex, hipStream_t stream) {
     dim3 grid(n_blocks), block(kBlock);
-    // gv: the scene holds a ConvexVolume whose boundary is not the inline sphere.  The lean form (no mesh branch) serves the launches
-    // that cannot meet a mesh hit: the camera-ray pass, the class-A part of a later pass, every pass of a scene without meshes.
+    // gv: the scene holds a ConvexVolume whose boundary is not the inline sphere.  tex: some mesh takes its material from maps or has a
+    // normal map.  The lean form (no mesh branch) serves the launches that cannot meet a mesh hit: the camera-ray pass, the class-A
+    // part of a later pass, every pass of a scene without meshes.
     const bool lean = a.iter0 != 0u || a.part == 1u || a.S.n_meshes == 0;
-#define PT_WF_MAIN2(G, V, M, R, I) hipLaunchKernelGGL((wf_main<false, G, V, M, R, I>), grid, block, 0, stream, a)
-#define PT_WF_MAIN(G, V, M, R) do { if (a.iter0) PT_WF_MAIN2(G, V, false, R, true); else PT_WF_MAIN2(G, V, M, R, false); } while (0)
     const bool rare = a.S.n_list_plane + a.S.n_list_volume > 0;          // (gv implies rare: it is a kind of ConvexVolume)
-    if (!rare) {
-        if (lean) { if (sig) PT_WF_MAIN(true, false, false, false); else PT_WF_MAIN(false, false, false, false); }
-        else      { if (sig) PT_WF_MAIN(true, false, true, false); else PT_WF_MAIN(false, false, true, false); }
-    } else if (lean) {
-        if (gv) { if (sig) PT_WF_MAIN(true, true, false, true); else PT_WF_MAIN(false, true, false, true); }
-        else    { if (sig) PT_WF_MAIN(true, false, false, true); else PT_WF_MAIN(false, false, false, true); }
-    } else {
-        if (gv) { if (sig) PT_WF_MAIN(true, true, true, true); else PT_WF_MAIN(false, true, true, true); }
-        else    { if (sig) PT_WF_MAIN(true, false, true, true); else PT_WF_MAIN(false, false, true, true); }
-    }
+#define PT_WF_MAIN2(G, V, M, R, I) hipLaunchKernelGGL((wf_main<false, G, V, M, R, I>), grid, block, 0, stream, a)
+#define PT_WF_SIG(V, M, R, I) do { if (sig) PT_WF_MAIN2(true, V, M, R, I); else PT_WF_MAIN2(false, V, M, R, I); } while (0)
+#define PT_WF_MESH(V, R) do { if (a.iter0) PT_WF_SIG(V, 0, R, true); else if (lean) PT_WF_SIG(V, 0, R, false); \
+                              else if (tex) PT_WF_SIG(V, 2, R, false); else PT_WF_SIG(V, 1, R, false); } while (0)
+    if (!rare) PT_WF_MESH(false, false);
+    else if (gv) PT_WF_MESH(true, true);
+    else PT_WF_MESH(false, true);
+#undef PT_WF_MESH
+#undef PT_WF_SIG
 #undef PT_WF_MAIN2
-#undef PT_WF_MAIN
     return hipGetLastError();
 }
 // big_lds_enabled: the calling context's record of the > 64 KB dynamic-LDS opt-in.  The attribute belongs to the
