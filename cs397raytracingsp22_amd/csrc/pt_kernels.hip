@@ -38,6 +38,9 @@
 #ifndef PT_MAIN_WAVES
 #define PT_MAIN_WAVES 6     // wf_main: waves per SIMD the register allocator must allow (A/B round 2: 4 -> 90 VGPRs 99.5 ms, 6 -> 80 VGPRs 97.4 ms on cfg2)
 #endif
+#ifndef PT_MAIN_WAVES_NOTEX
+#define PT_MAIN_WAVES_NOTEX 6 // wf_main with meshes but without maps (MESH = 1)
+#endif
 #ifndef PT_MAIN_WAVES_LEAN
 #define PT_MAIN_WAVES_LEAN 7  // wf_main without the mesh branch (camera-ray pass, class-A parts, scenes without meshes): 60 VGPRs, no scratch, no
                               // scalar spills (the full form: 80 / 12 B / 16).  6 / 7 / 8: cfg2 82.9 / 82.8 / 83.0 ms, cfg1 41.3 / 40.8 / 41.0
@@ -1476,7 +1479,7 @@ __device__ __forceinline__ void wf_pixel_of(const WfArgs& A, uint32_t pix, uint3
 // RARE = false: the scene holds no Plane and no ConvexVolume (their loop and the free-flight code are compiled out)
 // ITER0 = true: the camera-ray pass (Camera::generate_rays instead of a state load; always the lean form)
 template <bool LDS, bool SIG, bool GV, int MESH, bool RARE, bool ITER0>
-__global__ __launch_bounds__(kBlock, (MESH ? PT_MAIN_WAVES : PT_MAIN_WAVES_LEAN)) void wf_main(WfArgs A) {
+__global__ __launch_bounds__(kBlock, (MESH == 2 ? PT_MAIN_WAVES : (MESH == 1 ? PT_MAIN_WAVES_NOTEX : PT_MAIN_WAVES_LEAN))) void wf_main(WfArgs A) {
     const DScene& S = A.S;
     const DCamera& C = A.C;
     Bvh<LDS> B;            // only the mesh ROOT nodes are read here
@@ -1727,7 +1730,9 @@ __device__ __forceinline__ void bvh_bind(BvhNodesLds& B, const DScene& S, int) {
 // merged in memory at the end of a walk, u and v recomputed by one more triangle test): bit-exact, but cfg4 wf_trav
 // 270 -> 321 ms, HEAD 54 -> 67 ms; the slimmed state alone, one ray per lane: 310 / 63 ms and cfg2 28.4 -> 34 ms.  The
 // walker is bound by VALU issue and LDS bank conflicts of its random 32-byte node reads, not by uncovered latency.)
-template <int LDS, int BS>
+// MULTI = false: this launch walks ONE mesh (bit 0 of trav_mask alone): the step to a further mesh is compiled out and the world-space
+// ray is dead once it has been taken to object space (6 VGPRs of a 64-register budget)
+template <int LDS, int BS, bool MULTI>
 __global__ __launch_bounds__(BS, (BS == 256 ? PT_TRAV_WAVES : 4)) void wf_trav(WfArgs A) {
     const DScene& S = A.S;
     // Work distribution over the CONCATENATED queue (virtual indices; shard s owns [trav_pfx[s], trav_pfx[s+1])):
@@ -1812,7 +1817,7 @@ __global__ __launch_bounds__(BS, (BS == 256 ? PT_TRAV_WAVES : 4)) void wf_trav(W
                 // the ray entered SOME mesh's root box in wf_main; find the first one of THIS launch's meshes it enters
                 // (same root tests, same arithmetic; a ray that enters none of them has nothing to do here)
                 tm = 0;
-                if (enter_next_mesh(S, B, tm, o, d, t_min, t_max, too, tod, tinv, ti, tend, ttb, A.trav_mask)) {
+                if (enter_next_mesh(S, B, tm, o, d, t_min, t_max, too, tod, tinv, ti, tend, ttb, MULTI ? A.trav_mask : 1u) && (MULTI || tm == 0)) {
                     tbt = t_max; tbtri = -1; tbu = tbv = 0.0f;
                     te2 = S.meshes[tm].e2_begin;
                     B.node(ti, c0, c1);
@@ -1884,7 +1889,7 @@ __global__ __launch_bounds__(BS, (BS == 256 ? PT_TRAV_WAVES : 4)) void wf_trav(W
         if (have && ti >= tend) {
             if (tbtri >= 0) consider(best, tbt, S.meshes[tm].object_index, tbtri, tbu, tbv);
             tm++;
-            if (enter_next_mesh(S, B, tm, o, d, t_min, t_max, too, tod, tinv, ti, tend, ttb, A.trav_mask)) {
+            if (MULTI && enter_next_mesh(S, B, tm, o, d, t_min, t_max, too, tod, tinv, ti, tend, ttb, A.trav_mask)) {
                 tbt = t_max; tbtri = -1; tbu = tbv = 0.0f;
                 te2 = S.meshes[tm].e2_begin;
                 B.node(ti, c0, c1);
@@ -1916,7 +1921,7 @@ __global__ __launch_bounds__(BS, (BS == 256 ? PT_TRAV_WAVES : 4)) void wf_trav(W
 // LDS-busy time and the VALU-issue time of that kernel ADDING up to its duration instead of overlapping.  Here only the INTERIOR
 // nodes live in LDS (pt_device.h DScene.inodes: half the bytes, every link explicit), so two such blocks fit a CU — 8 waves per
 // SIMD — and a leaf is three 16-byte reads from the leaf pool in global memory (L2-resident: 11 of the ~96 steps of a drone ray).
-template <int BS>
+template <int BS, bool MULTI>
 __global__ __launch_bounds__(BS, 8) void wf_trav_i(WfArgs A) {
     const DScene& S = A.S;
     const uint32_t n_q = A.hdr[2];
@@ -1988,7 +1993,7 @@ __global__ __launch_bounds__(BS, 8) void wf_trav_i(WfArgs A) {
                 best.t = hr.t; best.obj = hr.obj; best.tri = -1; best.u = 0.0f; best.v = 0.0f;
                 tm = 0;
                 int ti, tend, ttb;
-                if (enter_next_mesh(S, B, tm, o, d, t_min, t_max, too, tod, tinv, ti, tend, ttb, A.trav_mask)) { start_mesh(); have = true; }
+                if (enter_next_mesh(S, B, tm, o, d, t_min, t_max, too, tod, tinv, ti, tend, ttb, MULTI ? A.trav_mask : 1u) && (MULTI || tm == 0)) { start_mesh(); have = true; }
             }
             wnext += min(avail, n_idle);
             if (wnext < wend) { const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)wnext); while (A.trav_pfx[wlo + 1] <= w) wlo++; }
@@ -2031,7 +2036,7 @@ __global__ __launch_bounds__(BS, 8) void wf_trav_i(WfArgs A) {
             if (tbtri >= 0) consider(best, tbt, S.meshes[tm].object_index, tbtri, tbu, tbv);
             tm++;
             int ti, tend, ttb;
-            if (enter_next_mesh(S, B, tm, o, d, t_min, t_max, too, tod, tinv, ti, tend, ttb, A.trav_mask)) start_mesh();
+            if (MULTI && enter_next_mesh(S, B, tm, o, d, t_min, t_max, too, tod, tinv, ti, tend, ttb, A.trav_mask)) start_mesh();
             else {
                 if (best.tri >= 0) {
                     Hit2 hw; hw.t = best.t; hw.obj = best.obj;
@@ -2616,25 +2621,31 @@ hipError_t launch_wf_main(const WfArgs& a, uint32_t n_blocks, bool sig, bool gv,
 // function ON THE CURRENT DEVICE, so it is kept per context (one context = one device), not per process.
 hipError_t launch_wf_trav(const WfArgs& a, uint32_t n_blocks, int lds_mode, size_t lds_bytes, bool* big_lds_enabled, hipStream_t stream) {
     dim3 grid(n_blocks), block(kBlock);
+    const bool multi = a.trav_mask != 1u || a.S.n_meshes > 32;      // more than mesh 0 to walk in this launch
     if (lds_mode == 3) {           // nodes in LDS, one 1024-thread block per CU
         if (!*big_lds_enabled) {
-            hipError_t e = hipFuncSetAttribute((const void*)wf_trav<2, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipError_t e = hipFuncSetAttribute((const void*)wf_trav<2, 1024, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e == hipSuccess) e = hipFuncSetAttribute((const void*)wf_trav<2, 1024, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return e;
             *big_lds_enabled = true;
         }
-        hipLaunchKernelGGL((wf_trav<2, 1024>), grid, dim3(1024), lds_bytes, stream, a);
+        if (multi) hipLaunchKernelGGL((wf_trav<2, 1024, true>), grid, dim3(1024), lds_bytes, stream, a);
+        else hipLaunchKernelGGL((wf_trav<2, 1024, false>), grid, dim3(1024), lds_bytes, stream, a);
     }
-    else if (lds_mode == 2) hipLaunchKernelGGL((wf_trav<2, 256>), grid, block, lds_bytes, stream, a);
-    else hipLaunchKernelGGL((wf_trav<0, 256>), grid, block, 0, stream, a);
+    else if (lds_mode == 2) { if (multi) hipLaunchKernelGGL((wf_trav<2, 256, true>), grid, block, lds_bytes, stream, a); else hipLaunchKernelGGL((wf_trav<2, 256, false>), grid, block, lds_bytes, stream, a); }
+    else { if (multi) hipLaunchKernelGGL((wf_trav<0, 256, true>), grid, block, 0, stream, a); else hipLaunchKernelGGL((wf_trav<0, 256, false>), grid, block, 0, stream, a); }
     return hipGetLastError();
 }
 hipError_t launch_wf_trav_i(const WfArgs& a, uint32_t n_blocks, size_t lds_bytes, bool* big_lds_enabled, hipStream_t stream) {
     if (!*big_lds_enabled) {       // the attribute belongs to the function on the current device: kept per context
-        hipError_t e = hipFuncSetAttribute((const void*)wf_trav_i<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute((const void*)wf_trav_i<1024, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)wf_trav_i<1024, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         *big_lds_enabled = true;
     }
-    hipLaunchKernelGGL((wf_trav_i<1024>), dim3(n_blocks), dim3(1024), lds_bytes, stream, a);
+    const bool multi = a.trav_mask != 1u || a.S.n_meshes > 32;
+    if (multi) hipLaunchKernelGGL((wf_trav_i<1024, true>), dim3(n_blocks), dim3(1024), lds_bytes, stream, a);
+    else hipLaunchKernelGGL((wf_trav_i<1024, false>), dim3(n_blocks), dim3(1024), lds_bytes, stream, a);
     return hipGetLastError();
 }
 hipError_t launch_wf_trav_f(const WfArgs& a, uint32_t n_blocks, hipStream_t stream) {
