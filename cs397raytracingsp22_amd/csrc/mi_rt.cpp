@@ -155,6 +155,7 @@ struct mi_ctx {
         bool debug_mask = false;                        // print tile-mask statistics
         bool dump_launches = false;                     // print every pipeline launch's duration (needs per-launch events)
         int split = 1;                                  // wf_main in two parts, class A beside the previous pass' walkers (0 = one launch per pass)
+        uint32_t tail_paths = 0xffffffffu;              // a pass that starts with at most this many live paths runs every path as far as it can inside the launch (0 = never; default: automatic)
         uint32_t nowait_blocks = 16384;                 // passes whose grid bound is at most this many blocks are launched without waiting for the previous header (0 = always wait)
         uint32_t spin_timeout_ms = 120000;              // header wait: give up after this long without progress
     } tune;
@@ -197,7 +198,7 @@ static int ctx_init(mi_ctx* c, const hipDeviceProp_t& prop) {
     if (const char* e = getenv("MI_RT_LDS_PAD_KB")) t.lds_pad = (uint32_t)atoi(e) * 1024u;
     env_u("MI_RT_WF_REFILL", t.refill_min);
     env_u("MI_RT_WF_FUSE_MAX", t.fuse_max); env_u("MI_RT_WF_FUSE_MIN", t.fuse_min);
-    env_i("MI_RT_WF_SPLIT", t.split); env_u("MI_RT_WF_NOWAIT_BLOCKS", t.nowait_blocks);
+    env_i("MI_RT_WF_SPLIT", t.split); env_u("MI_RT_WF_NOWAIT_BLOCKS", t.nowait_blocks); env_u("MI_RT_WF_TAIL_PATHS", t.tail_paths);
     env_i("MI_RT_WF_TRAV_LDS", t.trav_lds); env_i("MI_RT_WF_TRAV_BPC", t.trav_bpc); env_i("MI_RT_WF_TRAVF_BPC", t.travf_bpc); env_i("MI_RT_WF_KERNEL_TIMING", t.kernel_timing);
     t.global_bvh = getenv("MI_RT_GLOBAL_BVH") != nullptr;
     t.wf_stamps = getenv("MI_RT_WF_STAMPS") != nullptr;
@@ -1120,6 +1121,7 @@ static int render_tiles_wavefront(mi_ctx* c, const K1Args& k, const mi_camera_de
     // (cfg5 at 512 spp: 1 / 2 / 3 / 5 rounds -> 281.6 / 271.8 / 278.4 / 287.7 ms; the cfg1 scene at 1080p: 46.6 / 42.9 / 47.4 / 48.1 ms)
     a.fuse_max = c->tune.fuse_max ? c->tune.fuse_max : (c->S.n_meshes == 0 ? 2u : 1u);
     a.fuse_min = c->tune.fuse_min < 1 ? 1 : c->tune.fuse_min;
+    const uint32_t fuse_max_normal = a.fuse_max, fuse_min_normal = a.fuse_min;
     // Which meshes are walked how: the two-stage meshes (wf_trav_f + wf_replay), the rest through the reference's tree (wf_trav).
     const uint32_t all_meshes = c->S.n_meshes >= 32 ? 0xffffffffu : ((1u << c->S.n_meshes) - 1u);
     const uint32_t ts_mask = two_stage_mask(c, flags) & all_meshes;
@@ -1257,6 +1259,18 @@ static int render_tiles_wavefront(mi_ctx* c, const K1Args& k, const mi_camera_de
             else { grid_all = grid_a = (uint32_t)((uint64_t)last.live / kBlock) + 2u * (uint32_t)kWfShards; }
             if (it == 0) { grid_all = last.blocks; grid_a = 0; }
             if (grid_all == 0) break;
+            // THE TAIL.  Once the live paths no longer fill the chip (last.live bounds this pass' input: paths only end), thin waves
+            // cost nothing — there is nobody to give their lanes to — while every further pass costs two launches and a header.
+            // So each wave keeps shading as long as ANY of its lanes can go on (a path that enters a mesh root still parks for
+            // the walker).  Per path the operations and their order are those of the pass-by-pass schedule.  Without meshes
+            // nothing ever parks: this launch ends every path and is the last one.
+            // Threshold (MI_RT_WF_TAIL_PATHS): without meshes 4 Mi paths, the size below which passes are launched without waiting
+            // (cfg1 as BASELINE states it, 400x400 / 16 spp: 0.64 ms at 0, 0.55 at 64 Ki ... 2 Mi, 0.49 from 3 Mi on; cfg1 / cfg5 at
+            // 1080p unchanged up to 8 Mi); with meshes 1 Mi (a 1/8 share of cfg2: 11.0 ms up to 2 Mi, 11.1 at 4 Mi, 11.3 at 8 Mi).
+            const uint32_t tail_paths = c->tune.tail_paths != 0xffffffffu ? c->tune.tail_paths : (have_walkers ? (1u << 20) : (4u << 20));
+            const bool tail = it > 0 && tail_paths != 0 && last.live <= tail_paths;      // (the camera pass in this form too: 0.49 -> 0.58 ms on cfg1 as stated)
+            a.fuse_max = tail ? cam->path_depth + 2u : fuse_max_normal;
+            a.fuse_min = tail ? 1u : fuse_min_normal;
             a.st_in = a.iter0 ? nullptr : bufs[cur];
             a.st_out = bufs[cur ^ 1];
             a.n_blocks_in = grid_all;
@@ -1301,6 +1315,7 @@ static int render_tiles_wavefront(mi_ctx* c, const K1Args& k, const mi_camera_de
             }
             cur ^= 1;
             a.iter0 = 0;
+            if (tail && !have_walkers) { it++; break; }
         }
         WF_TIMED(2, launch_wf_reduce(a, s0 == 0, s0 + a.s_count >= spp, stream));
         // the headers not read yet (statistics; passes launched behind the one that ended every path are not counted)

@@ -12,22 +12,28 @@ from cs397raytracingsp22_amd import Context, Lambertian, StaticMesh, abi, cgmath
 pytestmark = pytest.mark.gpu
 
 
-def render_with_mode(mode, flat, cam, seed):
-    old = os.environ.get("MI_RT_WF_TRAV_LDS")
-    os.environ["MI_RT_WF_TRAV_LDS"] = str(mode)
+def render_with_env(env, flat, cam, seed, flags=0):
+    """A context of its own created under the given developer knobs (read once in mi_ctx_create)."""
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update({k: str(v) for k, v in env.items()})
     try:
         ctx = Context(0)
     finally:
-        if old is None:
-            del os.environ["MI_RT_WF_TRAV_LDS"]
-        else:
-            os.environ["MI_RT_WF_TRAV_LDS"] = old
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
     try:
         ctx.upload(flat)
-        f32, _, sig, _ = ctx.render(cam, seed=seed, want_sig=True, flags=abi.MI_OPT_REFERENCE_WALK)
+        f32, _, sig, _ = ctx.render(cam, seed=seed, want_sig=True, flags=flags)
         return f32, sig
     finally:
         ctx.close()
+
+
+def render_with_mode(mode, flat, cam, seed):
+    return render_with_env({"MI_RT_WF_TRAV_LDS": mode}, flat, cam, seed, flags=abi.MI_OPT_REFERENCE_WALK)
 
 
 def test_walker_storage_modes_agree_with_the_oracle_teapot(orc):
@@ -68,3 +74,21 @@ def test_drone_takes_the_interior_in_lds_walker_and_matches(orc, gpu_ctx):
     assert int((sig != rsig).sum()) == 0
     _, sig3 = render_with_mode(3, flat, sc.camera, 2)
     assert np.array_equal(sig3, rsig)
+
+
+@pytest.mark.parametrize("scene", ["cfg1", "cfg2", "cfg5", "head"])
+def test_pass_schedules_agree_with_the_oracle(orc, scene):
+    """The pass-by-pass schedule (every pass through the HBM path state, one or two in-launch rounds), the tail schedule (a pass
+    that no longer fills the chip runs every path as far as it can inside one launch — what frames this small take by default)
+    and a schedule that waits for every header give the same paths."""
+    sc = {"cfg1": lambda: scenes.config1(160, 96, 16, 8), "cfg2": lambda: scenes.config2(160, 96, 16, 10),
+          "cfg5": lambda: scenes.config5(96, 64, 8, 50), "head": lambda: scenes.head_scene(96, 96, 8, 10)}[scene]()
+    flat = sc.flatten()
+    _, _, rsig, _ = orc.OracleScene(flat).render(sc.camera, seed=9)
+    ref = None
+    for env in ({"MI_RT_WF_TAIL_PATHS": 0}, {"MI_RT_WF_TAIL_PATHS": 4000}, {"MI_RT_WF_TAIL_PATHS": 1 << 22},
+                {"MI_RT_WF_TAIL_PATHS": 0, "MI_RT_WF_NOWAIT_BLOCKS": 0}):
+        f32, sig = render_with_env(env, flat, sc.camera, 9)
+        assert int((sig != rsig).sum()) == 0, f"{env}: paths differ from the oracle"
+        ref = f32 if ref is None else ref
+        assert np.array_equal(f32, ref), env
