@@ -95,7 +95,7 @@ struct FConst { float E2, L, cx, cy, cz, R; };
 
 // Binned-SAH hierarchy over the triangles' boxes, DFS pre-order with skip links, appended to `fnodes` (8 floats per node:
 // {bmin.xyz, skip}{bmax.xyz, leaf}); leaf = (first << 3) | (count - 1) >= 0 indexes `ftris`, interior = -1.  Skip links are
-// indices into `fnodes`.  `ftris` receives the leaves' triangles in leaf order, 12 floats each: {a.xyz, bits of the
+// indices into `fnodes`.  (The builder's form; the device gets the 16-byte quantised nodes of fq_encode below.)  `ftris` receives the leaves' triangles in leaf order, 12 floats each: {a.xyz, bits of the
 // triangle's index}{e1.xyz, 0}{e2.xyz, 0} — the reference's operands exactly as the reference walk reads them.
 struct FTree {
     const float* tris;                   // this mesh's triangles, 12 floats each: {a, 0}{e1, 0}{e2, 0}
@@ -227,6 +227,56 @@ struct FTree {
         return mid;
     }
 };
+
+// What the device walks: the F-nodes QUANTISED to 16 bytes — {qmin.x | qmin.y << 16, qmin.z | qmax.x << 16, qmax.y | qmax.z << 16, link},
+// link = the skip index of an interior node, 0x80000000 | (first << 3 | count - 1) for a leaf (whose successor is the next node
+// either way).  A coordinate decodes as fmaf((float)q, s, b): ONE correctly rounded operation, the same on host and device, with
+// s a power of two per mesh and b the F-root's lower corner.  The encoder rounds OUTWARD against that very decode, so the decoded
+// box CONTAINS the node's box, and the padded slab test — evaluated on the decoded box with the arithmetic it always had — is
+// monotone in the box (IEEE rounding is monotone: a lower bmin or higher bmax can only move an axis' entry earlier and its exit
+// later): every ray that passes the test on the exact box passes it on the decoded one.  The bound above therefore holds
+// unchanged; the grid costs a few false-positive node visits (1/65534 of the mesh's extent per face).  Why quantise at all: the
+// walk is bound by L1 tag look-ups — one per lane and load INSTRUCTION — and a 32-byte node takes two loads.
+struct FQuant { float s, bx, by, bz; };
+inline float fq_decode(uint32_t q, float s, float b) { return fmaf((float)q, s, b); }
+// `fnodes`: n float nodes as FTree emits them (node 0 = the root, whose box bounds every other); `out` receives 4 words per node.
+// false: the mesh cannot be put on the grid (non-finite bounds, or a face that does not fit 16 bits) — it does not qualify then.
+inline bool fq_encode(const float* fnodes, size_t n, FQuant* g, std::vector<uint32_t>* out) {
+    if (n == 0) { *g = FQuant{ 1.0f, 0.0f, 0.0f, 0.0f }; return true; }
+    const Box root = get_box(fnodes);
+    const double ext = std::max((double)root.mx.x - (double)root.mn.x, std::max((double)root.mx.y - (double)root.mn.y, (double)root.mx.z - (double)root.mn.z));
+    if (!std::isfinite(ext) || !std::isfinite(root.mn.x) || !std::isfinite(root.mn.y) || !std::isfinite(root.mn.z)) return false;
+    int k = -126;
+    if (ext > 0.0) { int e; (void)std::frexp(ext / 65534.0, &e); k = std::max(e, -126); }      // ext / 65534 <= 2^e
+    if (k > 100) return false;
+    g->s = std::ldexp(1.0f, k); g->bx = root.mn.x; g->by = root.mn.y; g->bz = root.mn.z;
+    const float b3[3] = { g->bx, g->by, g->bz };
+    out->reserve(out->size() + n * 4);
+    for (size_t i = 0; i < n; i++) {
+        const float* nd = fnodes + i * 8;
+        uint32_t q[6];
+        for (int a = 0; a < 3; a++) {
+            const float lo = nd[a], hi = nd[4 + a];
+            if (!std::isfinite(lo) || !std::isfinite(hi)) return false;
+            double ql = std::floor(((double)lo - (double)b3[a]) / (double)g->s), qh = std::ceil(((double)hi - (double)b3[a]) / (double)g->s);
+            ql = std::min(std::max(ql, 0.0), 65535.0); qh = std::min(std::max(qh, 0.0), 70000.0);
+            uint32_t l = (uint32_t)ql, h = (uint32_t)qh;
+            while (l > 0 && fq_decode(l, g->s, b3[a]) > lo) l--;
+            if (fq_decode(l, g->s, b3[a]) > lo) return false;
+            while (h <= 65535u && fq_decode(h, g->s, b3[a]) < hi) h++;
+            if (h > 65535u) return false;
+            q[a] = l; q[3 + a] = h;
+        }
+        int skip, leaf; memcpy(&skip, &nd[3], 4); memcpy(&leaf, &nd[7], 4);
+        out->push_back(q[0] | (q[1] << 16)); out->push_back(q[2] | (q[3] << 16)); out->push_back(q[4] | (q[5] << 16));
+        out->push_back(leaf >= 0 ? (0x80000000u | (uint32_t)leaf) : (uint32_t)skip);
+    }
+    return true;
+}
+inline Box fq_box(const uint32_t* w, const FQuant& g) {
+    return Box{ V3{ fq_decode(w[0] & 0xffffu, g.s, g.bx), fq_decode(w[0] >> 16, g.s, g.by), fq_decode(w[1] & 0xffffu, g.s, g.bz) },
+                V3{ fq_decode(w[1] >> 16, g.s, g.bx), fq_decode(w[2] & 0xffffu, g.s, g.by), fq_decode(w[2] >> 16, g.s, g.bz) } };
+}
 
 // The per-ray padding of pass 1 (the same f32 expression runs on the device: pt_kernels.hip two_stage_pad).
 // Returns false when the bound does not apply to this ray (B > 1/2, or anything non-finite): reference walk.

@@ -41,6 +41,7 @@ hipError_t launch_phong(const K1Args& a, uint32_t n_blocks, bool sig, hipStream_
 hipError_t launch_branch(const K1Args& a, uint32_t n_blocks, uint32_t path_samples, bool sig, hipStream_t stream);
 hipError_t launch_wf_trav(const WfArgs& a, uint32_t n_blocks, int lds_mode, size_t lds_bytes, bool* big_lds_enabled, hipStream_t stream);
 hipError_t launch_wf_trav_i(const WfArgs& a, uint32_t n_blocks, size_t lds_bytes, bool* big_lds_enabled, hipStream_t stream);
+hipError_t launch_wf_filter_f(const WfArgs& a, uint32_t blocks_per_shard, hipStream_t stream);
 hipError_t launch_wf_trav_f(const WfArgs& a, uint32_t n_blocks, hipStream_t stream);
 hipError_t launch_wf_replay(const WfArgs& a, uint32_t n_blocks, hipStream_t stream);
 hipError_t launch_wf_prefix(uint32_t* out_count, uint32_t* trav_count, uint32_t* in_count, uint32_t* in_blkpfx,
@@ -91,7 +92,8 @@ struct mi_ctx {
     int device = 0;
     hipStream_t stream = nullptr;            // own stream for mi_render
     hipStream_t aux_stream = nullptr;        // wavefront pipeline: the class-A part of a pass runs here, beside the walkers of the previous pass
-    hipEvent_t ev_pfx = nullptr, ev_part = nullptr;
+    hipStream_t aux2_stream = nullptr;       // ... and wf_trav_f here, beside wf_trav (scenes with meshes of both kinds)
+    hipEvent_t ev_pfx = nullptr, ev_part = nullptr, ev_travf = nullptr;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     bool ev_recorded = false;
 
@@ -155,6 +157,7 @@ struct mi_ctx {
         bool debug_mask = false;                        // print tile-mask statistics
         bool dump_launches = false;                     // print every pipeline launch's duration (needs per-launch events)
         int split = 1;                                  // wf_main in two parts, class A beside the previous pass' walkers (0 = one launch per pass)
+        int conc = 1, conc_trav_bpc = 0, conc_travf_bpc = 0;   // wf_trav and wf_trav_f on two streams (0 = one after the other); their blocks per CU then (0 = the usual)
         uint32_t tail_paths = 0xffffffffu;              // a pass that starts with at most this many live paths runs every path as far as it can inside the launch (0 = never; default: automatic)
         uint32_t nowait_blocks = 16384;                 // passes whose grid bound is at most this many blocks are launched without waiting for the previous header (0 = always wait)
         uint32_t spin_timeout_ms = 120000;              // header wait: give up after this long without progress
@@ -180,6 +183,8 @@ static int ctx_init(mi_ctx* c, const hipDeviceProp_t& prop) {
     HIP_TRY(hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&c->ev_pfx, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&c->ev_part, hipEventDisableTiming));
+    HIP_TRY(hipStreamCreateWithFlags(&c->aux2_stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_travf, hipEventDisableTiming));
     HIP_TRY(hipEventCreate(&c->ev_start));
     HIP_TRY(hipEventCreate(&c->ev_stop));
     HIP_TRY(hipEventCreate(&c->ev_t0));
@@ -199,6 +204,7 @@ static int ctx_init(mi_ctx* c, const hipDeviceProp_t& prop) {
     env_u("MI_RT_WF_REFILL", t.refill_min);
     env_u("MI_RT_WF_FUSE_MAX", t.fuse_max); env_u("MI_RT_WF_FUSE_MIN", t.fuse_min);
     env_i("MI_RT_WF_SPLIT", t.split); env_u("MI_RT_WF_NOWAIT_BLOCKS", t.nowait_blocks); env_u("MI_RT_WF_TAIL_PATHS", t.tail_paths);
+    env_i("MI_RT_WF_CONC", t.conc); env_i("MI_RT_WF_CONC_TRAV_BPC", t.conc_trav_bpc); env_i("MI_RT_WF_CONC_TRAVF_BPC", t.conc_travf_bpc);
     env_i("MI_RT_WF_TRAV_LDS", t.trav_lds); env_i("MI_RT_WF_TRAV_BPC", t.trav_bpc); env_i("MI_RT_WF_TRAVF_BPC", t.travf_bpc); env_i("MI_RT_WF_KERNEL_TIMING", t.kernel_timing);
     t.global_bvh = getenv("MI_RT_GLOBAL_BVH") != nullptr;
     t.wf_stamps = getenv("MI_RT_WF_STAMPS") != nullptr;
@@ -268,6 +274,8 @@ extern "C" void mi_ctx_destroy(mi_ctx* c) {
     if (c->ev_pfx) (void)hipEventDestroy(c->ev_pfx);
     if (c->ev_part) (void)hipEventDestroy(c->ev_part);
     if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
+    if (c->ev_travf) (void)hipEventDestroy(c->ev_travf);
+    if (c->aux2_stream) (void)hipStreamDestroy(c->aux2_stream);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -290,9 +298,10 @@ extern "C" int mi_scene_upload(mi_ctx* c, const mi_scene_desc* d) {
     std::vector<DMaterial> mats((size_t)d->n_materials);
     std::vector<DMesh> meshes((size_t)d->n_meshes);
     std::vector<DMeshF> meshf((size_t)d->n_meshes);
-    struct MeshBuild { std::vector<float> nodes, fnodes, ftris; bool qualifies = false, default_ts = false; int inode_end = 0; };
+    struct MeshBuild { std::vector<float> nodes, fnodes, ftris; std::vector<uint32_t> fq; bool qualifies = false, default_ts = false; int inode_end = 0; };
     std::vector<MeshBuild> mb((size_t)d->n_meshes);
-    std::vector<float> nodes, tris, fnodes, ftris, e2s, inodes, lnodes;
+    std::vector<float> nodes, tris, ftris, e2s, inodes, lnodes;
+    std::vector<uint32_t> fnodes;              // the F-trees as the device walks them: 4 words per node (bvh_build.hpp fq_encode)
     std::vector<DTriAttr> attrs;
     std::vector<DTexture> texs((size_t)d->n_textures);
     std::vector<uint8_t> texels;
@@ -405,10 +414,14 @@ extern "C" int mi_scene_upload(mi_ctx* c, const mi_scene_desc* d) {
             const double b_ref = 7.0 * 5.9604645e-08 * (double)fc.E2 * (std::sqrt(fro) * 8.0) * 1.0e4;
             const bool affine = s.inv_transform[3] == 0.0f && s.inv_transform[7] == 0.0f && s.inv_transform[11] == 0.0f && s.inv_transform[15] == 1.0f;
             B.qualifies = affine && std::isfinite(b_ref) && b_ref <= 0.05 && s.n_triangles < (1 << 24) && std::isfinite(fc.R) && std::isfinite(fc.L);
+            build::FQuant fq{ 1.0f, 0.0f, 0.0f, 0.0f };
+            if (B.qualifies) B.qualifies = build::fq_encode(B.fnodes.data(), B.fnodes.size() / 8, &fq, &B.fq);
+            F.qs = fq.s; F.qbx = fq.bx; F.qby = fq.by; F.qbz = fq.bz;
+            B.fnodes.clear(); B.fnodes.shrink_to_fit();
             B.default_ts = B.qualifies && s.n_triangles >= 1024;        // below that the reference's tree sits in LDS and the F-tree does not pay
             F.qualifies = B.qualifies ? 1 : 0;
             F.E2 = fc.E2; F.L = fc.L; F.cx = fc.cx; F.cy = fc.cy; F.cz = fc.cz; F.R = fc.R;
-            if (!B.qualifies) { B.fnodes.clear(); B.ftris.clear(); }
+            if (!B.qualifies) { B.fq.clear(); B.ftris.clear(); }
         }
     }
     // Pool placement: meshes walked through the reference's tree first, so that one LDS window over the head of the node
@@ -455,7 +468,7 @@ extern "C" int mi_scene_upload(mi_ctx* c, const mi_scene_desc* d) {
             MeshBuild& B = mb[(size_t)mi];
             DMesh& M = meshes[(size_t)mi];
             DMeshF& F = meshf[(size_t)mi];
-            const int nbase = (int)(nodes.size() / 8), fbase = (int)(fnodes.size() / 8);
+            const int nbase = (int)(nodes.size() / 8), fbase = (int)(fnodes.size() / 4);
             M.node_begin = nbase;
             for (size_t k = 0; k < B.nodes.size(); k += 8) { int sk; memcpy(&sk, &B.nodes[k + 3], 4); sk += nbase; memcpy(&B.nodes[k + 3], &sk, 4); }
             // leaf nodes carry {a, skip}{e1, tri} instead of their (never tested) box; e2 goes to its own small pool
@@ -504,12 +517,12 @@ extern "C" int mi_scene_upload(mi_ctx* c, const mi_scene_desc* d) {
             }
             nodes.insert(nodes.end(), B.nodes.begin(), B.nodes.end());
             M.node_end = (int)(nodes.size() / 8);
-            for (size_t k = 0; k < B.fnodes.size(); k += 8) { int sk; memcpy(&sk, &B.fnodes[k + 3], 4); sk += fbase; memcpy(&B.fnodes[k + 3], &sk, 4); }
+            for (size_t k = 0; k < B.fq.size(); k += 4) if (!(B.fq[k + 3] & 0x80000000u)) B.fq[k + 3] += (uint32_t)fbase;      // interior nodes: skip links into the pool
             F.fnode_begin = fbase; F.ftri_begin = (int)(ftris.size() / 12);
-            fnodes.insert(fnodes.end(), B.fnodes.begin(), B.fnodes.end());
+            fnodes.insert(fnodes.end(), B.fq.begin(), B.fq.end());
             ftris.insert(ftris.end(), B.ftris.begin(), B.ftris.end());
-            F.fnode_end = (int)(fnodes.size() / 8);
-            B.nodes.clear(); B.nodes.shrink_to_fit(); B.fnodes.clear(); B.ftris.clear();
+            F.fnode_end = (int)(fnodes.size() / 4);
+            B.nodes.clear(); B.nodes.shrink_to_fit(); B.fq.clear(); B.ftris.clear();
         }
     }
 
@@ -729,7 +742,7 @@ extern "C" int mi_scene_upload(mi_ctx* c, const mi_scene_desc* d) {
     c->S.meshf = (const DMeshF*)(b + off_meshf);
     c->S.fnodes = (const float*)(b + off_fnodes);
     c->S.ftris = (const float*)(b + off_ftris);
-    c->S.n_fnodes = (int)(fnodes.size() / 8);
+    c->S.n_fnodes = (int)(fnodes.size() / 4);
     c->S.nodes = (const float*)(b + off_nodes);
     c->S.e2s = (const float*)(b + off_e2);
     c->S.inodes = (const float*)(b + off_inodes);
@@ -1164,6 +1177,8 @@ static int render_tiles_wavefront(mi_ctx* c, const K1Args& k, const mi_camera_de
     if (c->tune.trav_bpc > 0) trav_bpc = (uint32_t)c->tune.trav_bpc;
     const uint32_t trav_blocks = (uint32_t)c->n_cus * trav_bpc;
     const uint32_t travf_blocks = (uint32_t)c->n_cus * (c->tune.travf_bpc > 0 ? (uint32_t)c->tune.travf_bpc : 6u), replay_blocks = (uint32_t)c->n_cus * 8u;
+    const uint32_t conc_trav_bpc = c->tune.conc_trav_bpc > 0 ? (uint32_t)c->tune.conc_trav_bpc : trav_bpc;
+    const uint32_t conc_travf_bpc = c->tune.conc_travf_bpc > 0 ? (uint32_t)c->tune.conc_travf_bpc : travf_blocks / (uint32_t)c->n_cus;
 
     // per-kernel timing: one event pair per launch, summed after the frame
     size_t ev_used = 0;
@@ -1301,16 +1316,35 @@ static int render_tiles_wavefront(mi_ctx* c, const K1Args& k, const mi_camera_de
             if (have_walkers && c->tune.split != 0) HIP_TRY(hipEventRecord(c->ev_pfx, stream));
             // persistent walkers; they leave at once when the queue is empty.  Successive launches merge their meshes' hits
             // into the hit record (strictly closer wins, ties go to the lower Scene.objects index: order-independent)
-            if (ref_mask || c->S.n_meshes > 32) {      // meshes 32, 33, ... have no mask bit: they always take the reference walk
+            const bool ref_walk = ref_mask || c->S.n_meshes > 32;      // meshes 32, 33, ... have no mask bit: they always take the reference walk
+            // Meshes of both kinds: wf_trav and wf_trav_f read the same queue and write different things (the hit record / the
+            // candidate lists; each has its own queue cursor), so they go to two streams and wf_replay, which merges into the hit
+            // record, follows both.  With full grids the F-tree walkers move in as the reference walkers run out of queue and leave
+            // (HEAD 98.5 -> 96.5 ms).  Sharing every CU from the start — half the wave slots each — gains nothing: 68 ms for the
+            // pair, exactly the 43 + 25 ms they take one after the other (VALU issue 0.71 + 0.34: together they saturate it).
+            const bool side_by_side = ref_walk && ts_mask && c->tune.conc != 0;
+            if (side_by_side) {
+                HIP_TRY(hipEventRecord(c->ev_pfx, stream));
+                HIP_TRY(hipStreamWaitEvent(c->aux2_stream, c->ev_pfx, 0));
+            }
+            if (ref_walk) {
                 a.trav_mask = ref_mask;
-                if (trav_lds_mode == 4) WF_TIMED(1, launch_wf_trav_i(a, trav_blocks, trav_lds_bytes, &c->big_lds_enabled_i, stream));
-                else WF_TIMED(1, launch_wf_trav(a, trav_blocks, trav_lds_mode, trav_lds_bytes, &c->big_lds_enabled, stream));
+                const uint32_t blocks = side_by_side ? (uint32_t)c->n_cus * conc_trav_bpc : trav_blocks;
+                if (trav_lds_mode == 4) WF_TIMED(1, launch_wf_trav_i(a, blocks, trav_lds_bytes, &c->big_lds_enabled_i, stream));
+                else WF_TIMED(1, launch_wf_trav(a, blocks, trav_lds_mode, trav_lds_bytes, &c->big_lds_enabled, stream));
             }
             if (ts_mask) {
                 a.trav_mask = ts_mask;
-                // the walkers of the first launch have advanced the shared queue cursor: rewind it (stream order)
-                if (ref_mask || c->S.n_meshes > 32) HIP_TRY(hipMemsetAsync(a.trav_head, 0, sizeof(uint32_t), stream));
-                WF_TIMED(3, launch_wf_trav_f(a, travf_blocks, stream));
+                // wf_filter_f keeps the queue entries that enter a two-stage mesh's root box; wf_trav_f and wf_replay work on that list
+                if (side_by_side) {
+                    WF_TIMED_ON(3, c->aux2_stream, launch_wf_filter_f(a, 8u, c->aux2_stream));
+                    WF_TIMED_ON(3, c->aux2_stream, launch_wf_trav_f(a, (uint32_t)c->n_cus * conc_travf_bpc, c->aux2_stream));
+                    HIP_TRY(hipEventRecord(c->ev_travf, c->aux2_stream));
+                    HIP_TRY(hipStreamWaitEvent(stream, c->ev_travf, 0));
+                } else {
+                    WF_TIMED(3, launch_wf_filter_f(a, 8u, stream));
+                    WF_TIMED(3, launch_wf_trav_f(a, travf_blocks, stream));
+                }
                 WF_TIMED(4, launch_wf_replay(a, replay_blocks, stream));
             }
             cur ^= 1;

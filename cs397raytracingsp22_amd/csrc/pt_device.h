@@ -107,8 +107,9 @@ struct alignas(16) DMeshF {
     float   E2, L;                    // max |e1||e2|, longest stored edge
     float   cx, cy, cz, R;            // bounding sphere of the vertices (object space)
     float   pad[2];
+    float   qs, qbx, qby, qbz;        // grid of the quantised F-nodes: coordinate = fmaf(q, qs, qb) (bvh_build.hpp fq_encode)
 };
-static_assert(sizeof(DMeshF) == 48, "DMeshF must be 48 bytes");
+static_assert(sizeof(DMeshF) == 64, "DMeshF must be 64 bytes");
 
 // per-triangle shading attributes, 20 floats = 5 float4
 struct alignas(16) DTriAttr {
@@ -255,7 +256,7 @@ struct WfArgs {
     const PT_CONST_AS uint32_t* in_blkpfx;   // [2*kWfShards + 1] exclusive prefix of ceil(count/256)
     uint32_t* out_count;  // [2*kWfShards] appended to st_out per (class, shard)
     uint32_t* trav_count; // [kWfShards] traversal queue length per shard
-    uint32_t* trav_head;  // [0]: consumption head over the CONCATENATED per-shard queues (wf_trav grabs 256 entries per atomic)
+    uint32_t* trav_head;  // [0]: consumption head over the CONCATENATED per-shard queues (wf_trav grabs 256 entries per atomic); [1]: the same for wf_trav_f
     const PT_CONST_AS uint32_t* trav_pfx;   // [kWfShards + 1] exclusive prefix of trav_count (host-built)
     const PT_CONST_AS uint32_t* hdr;   // [4] written by wf_prefix after every wf_main: blocks of the next pass, live paths, queue length
     uint32_t* trav_q;     // [cap] per-shard regions of positions (in st_out) whose ray entered a mesh root box

@@ -1825,7 +1825,6 @@ __global__ __launch_bounds__(BS, (BS == 256 ? PT_TRAV_WAVES : 4)) void wf_trav(W
                 }
             }
             wnext += min(avail, n_idle);
-            if (wnext < wend) { const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)wnext); while (A.trav_pfx[wlo + 1] <= w) wlo++; }
 #ifdef PT_TRAV_DIAG
             dg_refills++; dg_rlanes += (unsigned long long)__popcll(__builtin_amdgcn_ballot_w64(take));
 #endif
@@ -2110,7 +2109,7 @@ __device__ __forceinline__ bool slab_padded(f3 bmin, f3 bmax, f3 o, float rho, f
 // of entered meshes the bound does not cover for this ray.
 __device__ __forceinline__ bool enter_next_mesh_f(const DScene& S, int& m, uint32_t mask, f3 o, f3 d, float t_min, float t_max,
                                                   f3& oo, f3& od, f3& inv_d, float& rho_out, float& t_lo, float& t_hi,
-                                                  int& fi, int& fend, int& ftb, uint32_t& fallback) {
+                                                  int& fi, int& fend, int& ftb, uint32_t& fallback, float4& grid) {
     cf4_ptr gn = (cf4_ptr)S.nodes;
     for (; m < S.n_meshes && m < kTwoStageMaxMeshes; m++) {
         if (!((mask >> m) & 1u)) continue;
@@ -2127,9 +2126,82 @@ __device__ __forceinline__ bool enter_next_mesh_f(const DScene& S, int& m, uint3
         rho_out = rho;
         t_lo = t_min - dt; t_hi = t_max + dt;
         fi = F->fnode_begin; fend = F->fnode_end; ftb = F->ftri_begin;
+        grid = make_float4(F->qs, F->qbx, F->qby, F->qbz);
         return true;
     }
     return false;
+}
+
+// Does the ray enter the reference root box of ANY two-stage mesh in `mask`?  (The test enter_next_mesh_f starts with.)
+__device__ __forceinline__ bool enters_two_stage_root(const DScene& S, uint32_t mask, f3 o, f3 d, float t_min, float t_max) {
+    cf4_ptr gn = (cf4_ptr)S.nodes;
+    bool any = false;
+    for (int m = 0; m < S.n_meshes && m < kTwoStageMaxMeshes; m++) {
+        if (!((mask >> m) & 1u)) continue;
+        auto M = &S.meshes[m];
+        const f3 oo = xform_point(M->inv_transform, o), od = xform_vector(M->inv_transform, d);
+        f3 inv_d;
+        rcp3_exact(od.x, od.y, od.z, inv_d.x, inv_d.y, inv_d.z);
+        const float4 n0 = gn[2 * M->node_begin], n1 = gn[2 * M->node_begin + 1];
+        any = any | (int)(__float_as_int(n1.w) >= 0) | (int)slab(mk3(n0.x, n0.y, n0.z), mk3(n1.x, n1.y, n1.z), oo, inv_d, t_min, t_max);
+    }
+    return any;
+}
+
+// pass 0 of the two-stage traversal: the queue holds every ray that entered SOME mesh root; most of them are none of the
+// two-stage meshes' business (HEAD scene: 77 % miss the sphere's root box).  Inside the persistent walkers such an entry costs a
+// whole refill round — a chain of dependent loads (cursor, shard table, queue, path state) of ~16 us per wave for 64 rejected
+// rays: 10.5 of wf_trav_f's 23.5 ms.  This plain streaming pass over the queue — every load independent, one thread per entry —
+// applies the root test and keeps the rest: cand_hdr[j].x = the state position of the j-th kept ray, trav_head[2] = how many.
+// wf_trav_f and wf_replay then work on that list.  Blocks take the shards round-robin, so nothing is searched.
+__global__ __launch_bounds__(256) void wf_filter_f(WfArgs A) {
+    const DScene& S = A.S;
+    const float t_min = 0.001f, t_max = A.C.max_trace_dist;
+    const uint32_t cap = A.cap;
+    const uint32_t shard = blockIdx.x % (uint32_t)kWfShards, sub = blockIdx.x / (uint32_t)kWfShards, n_sub = gridDim.x / (uint32_t)kWfShards;
+    const uint32_t count = A.trav_pfx[shard + 1] - A.trav_pfx[shard];
+    const uint32_t lane = threadIdx.x & 63u;
+    // The kept entries are staged in LDS and leave in runs of >= 1024 behind ONE atomic on the list's counter (a single address
+    // retires ~90 atomics per microsecond: one per wave and 64 entries took 29 ms here)
+    __shared__ uint32_t buf[1024 + 256];
+    __shared__ uint32_t n_buf, g_base;
+    if (threadIdx.x == 0) n_buf = 0;
+    __syncthreads();
+    auto flush = [&]() {                                  // block-uniform call
+        const uint32_t n = n_buf;
+        if (threadIdx.x == 0 && n) g_base = atomicAdd(&A.trav_head[2], n);
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < n; i += 256u) A.cand_hdr[g_base + i] = make_uint2(buf[i], 0u);
+        __syncthreads();
+        if (threadIdx.x == 0) n_buf = 0;
+        __syncthreads();
+    };
+    for (uint32_t k0 = sub * 256u; k0 < count; k0 += n_sub * 256u) {
+        const uint32_t k = k0 + threadIdx.x;
+        uint32_t pos = 0;
+        bool keep = false;
+        if (k < count) {
+            pos = A.trav_q[(size_t)shard * A.region + k];
+            const float4 q0 = A.st_out[st_idx(0, pos, cap)], q1 = A.st_out[st_idx(1, pos, cap)];
+            keep = enters_two_stage_root(S, A.trav_mask, mk3(q0.x, q0.y, q0.z), mk3(q0.w, q1.x, q1.y), t_min, t_max);
+        }
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
+        uint32_t base = 0;
+        if (lane == 0 && m) base = atomicAdd(&n_buf, (uint32_t)__popcll(m));
+        base = (uint32_t)__shfl((int)base, 0);
+        if (keep) buf[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = pos;
+        __syncthreads();
+        if (n_buf >= 1024u) flush();
+    }
+    flush();
+}
+
+// A quantised F-node (bvh_build.hpp fq_encode): six 16-bit grid coordinates, decoded by one fmaf each — the operation the encoder
+// rounded outward against — and the link word.
+__device__ __forceinline__ void fq_box(float4 c, float4 g, f3& bmin, f3& bmax) {
+    const uint32_t w0 = __float_as_uint(c.x), w1 = __float_as_uint(c.y), w2 = __float_as_uint(c.z);
+    bmin = mk3(__builtin_fmaf((float)(w0 & 0xffffu), g.x, g.y), __builtin_fmaf((float)(w0 >> 16), g.x, g.z), __builtin_fmaf((float)(w1 & 0xffffu), g.x, g.w));
+    bmax = mk3(__builtin_fmaf((float)(w1 >> 16), g.x, g.y), __builtin_fmaf((float)(w2 & 0xffffu), g.x, g.z), __builtin_fmaf((float)(w2 >> 16), g.x, g.w));
 }
 
 // pass 1: persistent walkers over the traversal queue (work distribution and refill exactly as wf_trav)
@@ -2143,7 +2215,7 @@ __device__ __forceinline__ bool enter_next_mesh_f(const DScene& S, int& m, uint3
 // of stopping at the first one entered: wf_main +2.5 ms on cfg2, +1.2 ms on the HEAD scene, wf_trav_f only -0.3 ms.)
 __global__ __launch_bounds__(256, PT_TRAV_WAVES) void wf_trav_f(WfArgs A) {
     const DScene& S = A.S;
-    const uint32_t n_q = A.hdr[2];
+    const uint32_t n_q = A.trav_head[2];                 // the rays wf_filter_f kept
     const uint32_t n_waves = gridDim.x * 4u;
     uint32_t chunk = 256u;                               // as wf_trav: short queues are dealt out evenly
     if (n_q < n_waves * 256u) chunk = max(64u, ((n_q + n_waves - 1u) / n_waves + 63u) & ~63u);
@@ -2158,16 +2230,13 @@ __global__ __launch_bounds__(256, PT_TRAV_WAVES) void wf_trav_f(WfArgs A) {
     uint32_t wnext = wave_id * chunk, wend = min(wnext + chunk, n_q);
     bool drained = false;
     if (wnext >= n_q) { wnext = wend = 0; drained = true; }
-    // shard of the chunk's first entry, kept wave-uniform (SGPRs): a lane then finds its own shard with a step or two
-    // instead of an eight-deep chain of dependent vector loads at every refill
-    uint32_t wlo = drained ? 0u : wf_shard_of(A.trav_pfx, (uint32_t)__builtin_amdgcn_readfirstlane((int)wnext));
 
     bool have = false, atleaf = false;
     uint32_t vi = 0, pos = 0, nc = 0, fb = 0;
     f3 too = mk3(0.0f, 0.0f, 0.0f), tod = too, tinv = too;
     float trho = 0.0f, t_lo = 0.0f, t_hi = 0.0f;
     int tm = 0, fi = 0, fend = 0, ftb = 0;
-    float4 c0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), c1 = c0;
+    float4 c0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), tgrid = c0;      // c0: the node the lane stands on (16 bytes: ONE load per step)
     const int last_fnode = S.n_fnodes - 1;          // clamp for the load that follows the last node of a tree
 #ifdef PT_TRAV_DIAG
     unsigned long long dg_trips = 0, dg_bsteps = 0, dg_blanes = 0, dg_lsteps = 0, dg_llanes = 0, dg_refills = 0, dg_rlanes = 0, dg_walks = 0;
@@ -2184,32 +2253,29 @@ __global__ __launch_bounds__(256, PT_TRAV_WAVES) void wf_trav_f(WfArgs A) {
             if (wnext == wend) {
                 uint32_t base = n_q;
                 if (shared_part) {
-                    if (lane == 0) base = n_waves * chunk + atomicAdd(&A.trav_head[0], chunk);
+                    if (lane == 0) base = n_waves * chunk + atomicAdd(&A.trav_head[1], chunk);
                     base = (uint32_t)__shfl((int)base, 0);
                 }
                 if (base >= n_q) drained = true;
-                else { wnext = base; wend = min(base + chunk, n_q); wlo = wf_shard_of(A.trav_pfx, (uint32_t)__builtin_amdgcn_readfirstlane((int)base)); }
+                else { wnext = base; wend = min(base + chunk, n_q); }
             }
             const uint32_t avail = wend - wnext;
             const uint32_t rank = (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
             const bool take = !have && rank < avail;
             if (take) {
                 vi = wnext + rank;
-                uint32_t lo = wlo;
-                while (A.trav_pfx[lo + 1] <= vi) lo++;
-                pos = A.trav_q[(size_t)lo * A.region + (vi - A.trav_pfx[lo])];
+                pos = A.cand_hdr[vi].x;
                 const float4 q0 = A.st_out[st_idx(0, pos, cap)], q1 = A.st_out[st_idx(1, pos, cap)];
                 const f3 o = mk3(q0.x, q0.y, q0.z), d = mk3(q0.w, q1.x, q1.y);
                 nc = 0; fb = 0; tm = 0; atleaf = false;
-                if (enter_next_mesh_f(S, tm, A.trav_mask, o, d, t_min, t_max, too, tod, tinv, trho, t_lo, t_hi, fi, fend, ftb, fb)) {
-                    c0 = FN[2 * fi]; c1 = FN[2 * fi + 1];
+                if (enter_next_mesh_f(S, tm, A.trav_mask, o, d, t_min, t_max, too, tod, tinv, trho, t_lo, t_hi, fi, fend, ftb, fb, tgrid)) {
+                    c0 = FN[fi];
                     have = true;
                 } else {
                     A.cand_hdr[vi] = make_uint2(pos, fb << 8);          // entered none of these meshes (or only uncovered ones)
                 }
             }
             wnext += min(avail, n_idle);
-            if (wnext < wend) { const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)wnext); while (A.trav_pfx[wlo + 1] <= w) wlo++; }
 #ifdef PT_TRAV_DIAG
             dg_refills++; dg_rlanes += (unsigned long long)__popcll(__builtin_amdgcn_ballot_w64(take)); dg_walks += (unsigned long long)__popcll(__builtin_amdgcn_ballot_w64(take & have));
 #endif
@@ -2233,20 +2299,23 @@ __global__ __launch_bounds__(256, PT_TRAV_WAVES) void wf_trav_f(WfArgs A) {
 #ifdef PT_TRAV_DIAG
                 dg_bsteps++; dg_blanes += (unsigned long long)__popcll(__builtin_amdgcn_ballot_w64(act));
 #endif
-                const bool hit = slab_padded(mk3(c0.x, c0.y, c0.z), mk3(c1.x, c1.y, c1.z), too, trho, tinv, t_lo, t_hi);
-                const bool leaf = __float_as_int(c1.w) >= 0;
+                f3 bmin, bmax;
+                fq_box(c0, tgrid, bmin, bmax);
+                const bool hit = slab_padded(bmin, bmax, too, trho, tinv, t_lo, t_hi);
+                const int link = __float_as_int(c0.w);
+                const bool leaf = link < 0;
                 const bool stop = act & hit & leaf;                      // reached a leaf: its triangles are tested in a leaf step
-                const int nxt = hit ? fi + 1 : __float_as_int(c0.w);
+                const int nxt = (hit | leaf) ? fi + 1 : link;            // a leaf's successor is the next node either way
                 atleaf = atleaf | stop;
                 const bool move = act & !stop;
                 fi = move ? nxt : fi;
-                if (move) { const int k = min(fi, last_fnode); c0 = FN[2 * k]; c1 = FN[2 * k + 1]; }
+                if (move) c0 = FN[min(fi, last_fnode)];
             }
         } else if (have & atleaf) {
 #ifdef PT_TRAV_DIAG
             dg_lsteps++; dg_llanes += (unsigned long long)n_leaf;
 #endif
-            const int payload = __float_as_int(c1.w);
+            const int payload = __float_as_int(c0.w) & 0x7fffffff;
             const int first = ftb + (payload >> 3), count = (payload & 7) + 1;
             for (int k = 0; k < count; k++) {
                 const float4 t0 = FT[3 * (first + k)], t1 = FT[3 * (first + k) + 1], t2 = FT[3 * (first + k) + 2];
@@ -2259,14 +2328,14 @@ __global__ __launch_bounds__(256, PT_TRAV_WAVES) void wf_trav_f(WfArgs A) {
             }
             atleaf = false;
             fi = fi + 1;                                                  // a leaf's successor in pre-order
-            { const int k = min(fi, last_fnode); c0 = FN[2 * k]; c1 = FN[2 * k + 1]; }
+            c0 = FN[min(fi, last_fnode)];
         }
         if (have && !atleaf && fi >= fend) {
             tm++;
             const float4 q0 = A.st_out[st_idx(0, pos, cap)], q1 = A.st_out[st_idx(1, pos, cap)];
             const f3 o = mk3(q0.x, q0.y, q0.z), d = mk3(q0.w, q1.x, q1.y);
-            if (enter_next_mesh_f(S, tm, A.trav_mask, o, d, t_min, t_max, too, tod, tinv, trho, t_lo, t_hi, fi, fend, ftb, fb)) {
-                c0 = FN[2 * fi]; c1 = FN[2 * fi + 1];
+            if (enter_next_mesh_f(S, tm, A.trav_mask, o, d, t_min, t_max, too, tod, tinv, trho, t_lo, t_hi, fi, fend, ftb, fb, tgrid)) {
+                c0 = FN[fi];
             } else {
                 A.cand_hdr[vi] = make_uint2(pos, nc | (fb << 8));
                 have = false;
@@ -2284,7 +2353,7 @@ __global__ __launch_bounds__(256, PT_TRAV_WAVES) void wf_trav_f(WfArgs A) {
 // pass 2: one thread per queued ray
 __global__ __launch_bounds__(256) void wf_replay(WfArgs A) {
     const DScene& S = A.S;
-    const uint32_t n_q = A.hdr[2];
+    const uint32_t n_q = A.trav_head[2];                 // the rays wf_filter_f kept
     const float t_min = 0.001f, t_max = A.C.max_trace_dist;
     const uint32_t cap = A.cap;
     cf4_ptr RN = (cf4_ptr)S.nodes;
@@ -2434,7 +2503,7 @@ __global__ __launch_bounds__(256) void wf_prefix(uint32_t* __restrict__ out_coun
     const uint32_t a = out_count[t], b = out_count[kWfShards + t], q = trav_count[t];
     atomicAdd(&tot_b, b);
     out_count[t] = 0; out_count[kWfShards + t] = 0; trav_count[t] = 0;       // ready for the next wf_main
-    if (t == 0) trav_count[kWfShards] = 0;                                  // trav_head, the walkers' shared cursor
+    if (t < 4) trav_count[kWfShards + t] = 0;                               // trav_head[0] / [1]: the shared cursors of wf_trav / wf_trav_f; [2]: wf_filter_f's count
     in_count[t] = a; in_count[kWfShards + t] = b;
     const uint32_t va = (a + kBlock - 1) / kBlock, vb = (b + kBlock - 1) / kBlock;
     uint32_t x0 = va, x1 = vb, x2 = q, x3 = a + b;
@@ -2646,6 +2715,10 @@ hipError_t launch_wf_trav_i(const WfArgs& a, uint32_t n_blocks, size_t lds_bytes
     const bool multi = a.trav_mask != 1u || a.S.n_meshes > 32;
     if (multi) hipLaunchKernelGGL((wf_trav_i<1024, true>), dim3(n_blocks), dim3(1024), lds_bytes, stream, a);
     else hipLaunchKernelGGL((wf_trav_i<1024, false>), dim3(n_blocks), dim3(1024), lds_bytes, stream, a);
+    return hipGetLastError();
+}
+hipError_t launch_wf_filter_f(const WfArgs& a, uint32_t blocks_per_shard, hipStream_t stream) {
+    hipLaunchKernelGGL(wf_filter_f, dim3((uint32_t)kWfShards * blocks_per_shard), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 hipError_t launch_wf_trav_f(const WfArgs& a, uint32_t n_blocks, hipStream_t stream) {

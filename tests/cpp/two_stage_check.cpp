@@ -75,6 +75,15 @@ int main(int argc, char** argv) {
     FTree ft{ tris.data(), nt, &fnodes, &ftris, 0, 2, {}, {}, {} };
     const FConst fc = ft.run();
     const int n_ref = (int)(nodes.size() / 8), n_f = (int)(fnodes.size() / 8);
+    // the device walks the F-nodes quantised to 16 bytes (bvh_build.hpp fq_encode): so does this check
+    FQuant grid; std::vector<uint32_t> fq;
+    if (!fq_encode(fnodes.data(), (size_t)n_f, &grid, &fq)) { fprintf(stderr, "mesh does not fit the 16-bit grid\n"); return 3; }
+    for (int i = 0; i < n_f; i++) {                            // outward rounding, checked node by node
+        const Box e = get_box(&fnodes[(size_t)i * 8]), q = fq_box(&fq[(size_t)i * 4], grid);
+        if (!(q.mn.x <= e.mn.x && q.mn.y <= e.mn.y && q.mn.z <= e.mn.z && q.mx.x >= e.mx.x && q.mx.y >= e.mx.y && q.mx.z >= e.mx.z)) {
+            fprintf(stderr, "quantised node %d does not contain its box\n", i); return 4;
+        }
+    }
     const Box root = get_box(nodes.data());
 
     std::mt19937 rng(seed);
@@ -149,11 +158,13 @@ int main(int argc, char** argv) {
                 int i = 0;
                 while (i < n_f) {
                     const float* n = &fnodes[(size_t)i * 8];
+                    const Box qb = fq_box(&fq[(size_t)i * 4], grid);
+                    const float blo[3] = { qb.mn.x, qb.mn.y, qb.mn.z }, bhi[3] = { qb.mx.x, qb.mx.y, qb.mx.z };
                     f_nodes++;
                     float tmin = t_lo, tmax = t_hi;
                     const float ov[3] = { o.x, o.y, o.z }, ii[3] = { inv.x, inv.y, inv.z };
                     for (int a = 0; a < 3; a++) {
-                        const float t0 = ((n[a] - ov[a]) - pad.rho) * ii[a], t1 = ((n[4 + a] - ov[a]) + pad.rho) * ii[a];
+                        const float t0 = ((blo[a] - ov[a]) - pad.rho) * ii[a], t1 = ((bhi[a] - ov[a]) + pad.rho) * ii[a];
                         const bool sw = ii[a] < 0.0f;
                         const float ta = sw ? t1 : t0, tb = sw ? t0 : t1;
                         tmin = fmaxf(ta, tmin); tmax = fminf(tb, tmax);
