@@ -124,7 +124,6 @@ struct mi_ctx {
     // wavefront pipeline buffers
     void* d_wf_a = nullptr; size_t wf_a_bytes = 0;   // path state ping
     void* d_wf_b = nullptr; size_t wf_b_bytes = 0;   // path state pong
-    void* d_wf_q = nullptr; size_t wf_q_bytes = 0;   // traversal queue
     void* d_wf_samp = nullptr; size_t wf_samp_bytes = 0;
     void* d_wf_acc = nullptr; size_t wf_acc_bytes = 0;
     uint32_t* d_wf_cnt = nullptr;
@@ -258,7 +257,6 @@ extern "C" void mi_ctx_destroy(mi_ctx* c) {
     if (c->d_diag) (void)hipFree(c->d_diag);
     if (c->d_wf_a) (void)hipFree(c->d_wf_a);
     if (c->d_wf_b) (void)hipFree(c->d_wf_b);
-    if (c->d_wf_q) (void)hipFree(c->d_wf_q);
     if (c->d_wf_samp) (void)hipFree(c->d_wf_samp);
     if (c->d_wf_acc) (void)hipFree(c->d_wf_acc);
     if (c->d_cand) (void)hipFree(c->d_cand);
@@ -856,7 +854,7 @@ static void make_camera(const mi_camera_desc* cam, DCamera* C) {
 // frame, 531 M paths = 112 GB, is ONE batch), halved on allocation failure.
 static const int kHdrRing = 16;        // pinned header slots (wf_prefix -> host), one per pass in flight
 static const int kRunAhead = 3;        // passes the host may launch before it has read the header of an earlier one
-static const size_t kWfBytesPerPath = 2 * (size_t)kWfPlanes * sizeof(float4) + 2 * 4 + sizeof(float4);      // ping / pong state, two queues, sample slot
+static const size_t kWfBytesPerPath = 2 * (size_t)kWfPlanes * sizeof(float4) + sizeof(float4);      // ping / pong state, sample slot
 static const size_t kWfBytesPerPathTwoStage = (size_t)kCandMax * sizeof(uint2) + sizeof(uint2);     // candidates + header per queue slot
 
 // which meshes this render walks two-stage (bit m = live mesh m)
@@ -876,7 +874,7 @@ static int wf_alloc(mi_ctx* c, WfArgs& a, uint32_t spp, uint64_t max_state_bytes
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)8 << 30;
         // what this context already holds for the pipeline can be reused
-        free_b += c->wf_a_bytes + c->wf_b_bytes + c->wf_q_bytes + c->wf_samp_bytes + c->cand_bytes + c->cand_hdr_bytes;
+        free_b += c->wf_a_bytes + c->wf_b_bytes + c->wf_samp_bytes + c->cand_bytes + c->cand_hdr_bytes;
         max_paths = (uint64_t)((double)free_b * 0.6 / (double)per_path);
     }
     if (max_paths > (1ull << 31)) max_paths = 1ull << 31;           // 32-bit path indices
@@ -898,7 +896,6 @@ static int wf_alloc(mi_ctx* c, WfArgs& a, uint32_t spp, uint64_t max_state_bytes
         const size_t st_bytes = (size_t)kWfPlanes * sizeof(float4) * a.cap;
         int rc = ensure(&c->d_wf_a, &c->wf_a_bytes, st_bytes);
         if (rc == MI_OK) rc = ensure(&c->d_wf_b, &c->wf_b_bytes, st_bytes);
-        if (rc == MI_OK) rc = ensure(&c->d_wf_q, &c->wf_q_bytes, (size_t)a.cap * 4 * 2);      // queue of pass i is read while pass i + 1 fills the other
         if (rc == MI_OK) rc = ensure(&c->d_wf_samp, &c->wf_samp_bytes, (size_t)paths * sizeof(float4));
         if (rc == MI_OK) rc = ensure(&c->d_wf_acc, &c->wf_acc_bytes, (size_t)a.npix * sizeof(float4));
         if (rc == MI_OK && two_stage) rc = ensure(&c->d_cand, &c->cand_bytes, (size_t)a.cap * kCandMax * sizeof(uint2));
@@ -1114,7 +1111,7 @@ static int render_tiles_wavefront(mi_ctx* c, const K1Args& k, const mi_camera_de
     a.trav_pfx = d_trav_pfx;
     uint32_t* d_hdr = d_trav_pfx + S_ + 8;
     a.hdr = d_hdr;
-    a.trav_q = (uint32_t*)c->d_wf_q; a.samp = (float4*)c->d_wf_samp; a.accum = range.accum ? range.accum : (float4*)c->d_wf_acc;
+    a.samp = (float4*)c->d_wf_samp; a.accum = range.accum ? range.accum : (float4*)c->d_wf_acc;
     a.out = d_compact; a.sig = d_sig;
     a.tile_mask = nullptr;
     if (tile_masks(c, cam, flags, a.R.tiles_x)) {
@@ -1200,7 +1197,6 @@ static int render_tiles_wavefront(mi_ctx* c, const K1Args& k, const mi_camera_de
     uint64_t counts[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
     counts[4] = (uint64_t)a.npix * (range.end - range.begin); counts[5] = a.npix;
     const bool have_walkers = ref_mask || ts_mask || c->S.n_meshes > 32;
-    uint32_t* queues[2] = { (uint32_t*)c->d_wf_q, (uint32_t*)c->d_wf_q + a.cap };
     // Headers: wf_prefix stores {blocks, live paths, queue length, seq, class-B paths, class-A blocks} of every pass into a RING of
     // pinned host slots (slot = seq % kHdrRing), so the host may run a few passes ahead of the device and still read every header.
     struct PassHdr { uint32_t blocks, live, queue, live_b, blocks_a; };
@@ -1289,7 +1285,6 @@ static int render_tiles_wavefront(mi_ctx* c, const K1Args& k, const mi_camera_de
             a.st_in = a.iter0 ? nullptr : bufs[cur];
             a.st_out = bufs[cur ^ 1];
             a.n_blocks_in = grid_all;
-            a.trav_q = queues[it & 1u];
             // A pass after the first is launched in TWO PARTS.  Its class-A blocks (paths whose pending hit is a plain Triangle /
             // Plane: nothing a walker could still change) go to a second stream, ordered only behind the previous pass' wf_prefix:
             // they fill the CUs the persistent walkers of that pass leave idle as their queue runs out (a walker launch ends

@@ -255,11 +255,10 @@ struct WfArgs {
     const PT_CONST_AS uint32_t* in_count;    // [2*kWfShards] live paths per (class, shard) of st_in: A shards, then B shards
     const PT_CONST_AS uint32_t* in_blkpfx;   // [2*kWfShards + 1] exclusive prefix of ceil(count/256)
     uint32_t* out_count;  // [2*kWfShards] appended to st_out per (class, shard)
-    uint32_t* trav_count; // [kWfShards] traversal queue length per shard
+    uint32_t* trav_count; // [kWfShards] unused since the walkers take the class-B blocks directly (wf_slot); trav_head sits behind it
     uint32_t* trav_head;  // [0]: consumption head over the CONCATENATED per-shard queues (wf_trav grabs 256 entries per atomic); [1]: the same for wf_trav_f
-    const PT_CONST_AS uint32_t* trav_pfx;   // [kWfShards + 1] exclusive prefix of trav_count (host-built)
-    const PT_CONST_AS uint32_t* hdr;   // [4] written by wf_prefix after every wf_main: blocks of the next pass, live paths, queue length
-    uint32_t* trav_q;     // [cap] per-shard regions of positions (in st_out) whose ray entered a mesh root box
+    const PT_CONST_AS uint32_t* trav_pfx;   // [kWfShards + 1] exclusive prefix of the class-B counts (statistics)
+    const PT_CONST_AS uint32_t* hdr;   // [4] written by wf_prefix after every wf_main: blocks of the next pass, live paths, rays waiting for a mesh walk (= class-B paths)
     float4* samp;         // [s_count][npix] finished samples: L.xyz, signature bits
     float4* accum;        // [npix] running per-pixel sum (xyz) and signature sum (w bits)
     float*    out;        // compact framebuffer [tiles_padded][1024][3]

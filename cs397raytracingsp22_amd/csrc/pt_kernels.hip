@@ -1665,23 +1665,21 @@ __global__ __launch_bounds__(kBlock, (MESH == 2 ? PT_MAIN_WAVES : (MESH == 1 ? P
     //      from the back (one atomic per wave and class) ----
     const bool cls_a = alive && !enters && (best.tri == -1);       // next shade: plain Triangle / Plane hit
     const bool cls_b2 = alive && !cls_a;
-    // The three wave-aggregated appends (class A, class B, traversal queue) go out as ONE vector atomic
-    // with lanes 0..2 addressing the three counters: one round trip per wave instead of three in a row
-    // (a returning atomic takes ~3k cycles with every CU issuing them; hipcc waits after each one).
-    uint32_t ia, ib, qpos;
+    // The two wave-aggregated appends (class A, class B) go out as ONE vector atomic with lanes 0 and 1 addressing the two
+    // counters: one round trip per wave instead of two in a row (a returning atomic takes ~3k cycles with every CU issuing
+    // them; hipcc waits after each one).  There is no traversal queue: class B IS the set of rays that wait for a mesh walk
+    // (alive && enters — best.tri is still -1 here), and the walkers go through the class-B blocks of the next pass' table.
+    uint32_t ia, ib;
     {
-        const bool want_t = alive && enters;
-        const unsigned long long ma = __builtin_amdgcn_ballot_w64(cls_a), mb = __builtin_amdgcn_ballot_w64(cls_b2),
-                                 mt = __builtin_amdgcn_ballot_w64(want_t);
+        const unsigned long long ma = __builtin_amdgcn_ballot_w64(cls_a), mb = __builtin_amdgcn_ballot_w64(cls_b2);
         const uint32_t lane = threadIdx.x & 63;
-        uint32_t* ctr = lane == 0 ? &A.out_count[out_shard] : (lane == 1 ? &A.out_count[(uint32_t)kWfShards + out_shard] : &A.trav_count[out_shard]);
-        const uint32_t add = (uint32_t)__popcll(lane == 0 ? ma : (lane == 1 ? mb : mt));
+        uint32_t* ctr = lane == 0 ? &A.out_count[out_shard] : &A.out_count[(uint32_t)kWfShards + out_shard];
+        const uint32_t add = (uint32_t)__popcll(lane == 0 ? ma : mb);
         uint32_t base = 0;
-        if (lane < 3 && add != 0) base = atomicAdd(ctr, add);
+        if (lane < 2 && add != 0) base = atomicAdd(ctr, add);
         const unsigned long long below = (1ull << lane) - 1ull;
         ia = (uint32_t)__shfl((int)base, 0) + (uint32_t)__popcll(ma & below);
         ib = (uint32_t)__shfl((int)base, 1) + (uint32_t)__popcll(mb & below);
-        qpos = (uint32_t)__shfl((int)base, 2) + (uint32_t)__popcll(mt & below);
     }
     WF_STAMP(5);
     const size_t pos = (size_t)out_shard * A.region + (cls_a ? ia : (A.region - 1u - ib));
@@ -1695,7 +1693,6 @@ __global__ __launch_bounds__(kBlock, (MESH == 2 ? PT_MAIN_WAVES : (MESH == 1 ? P
         if (!cls_a) *st_tri(A.st_out, pos, cap) = best.tri;
         if (SIG) *st_sig(A.st_out, pos, cap) = P.sig;
     }
-    if (alive && enters) A.trav_q[(size_t)out_shard * A.region + qpos] = (uint32_t)pos;
 #ifdef PT_WF_STAMPS
     WF_STAMP(6);       // waits for the state stores too
     if (A.diag && (bid & 63u) == 0u && threadIdx.x == 0) {
@@ -1707,11 +1704,25 @@ __global__ __launch_bounds__(kBlock, (MESH == 2 ? PT_MAIN_WAVES : (MESH == 1 ? P
 #endif
 }
 
-// Which shard's queue region holds virtual index v of the concatenated traversal queue: wave-uniform v, scalar loads.
-__device__ __forceinline__ uint32_t wf_shard_of(const PT_CONST_AS uint32_t* pfx, uint32_t v) {
-    uint32_t lo = 0, hi = (uint32_t)kWfShards;
-    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (pfx[mid] <= v) lo = mid; else hi = mid; }
+// The walkers' work list.  The rays that wait for a mesh walk are exactly the class-B paths of the pass' output, and wf_prefix
+// has just tabulated those for the next wf_main (in_count / in_blkpfx, entries kWfShards .. 2 kWfShards - 1: per shard, whole
+// blocks of 256).  So the walkers take SLOTS: slot v = lane v % 256 of class-B block v / 256; the block's table entry gives the
+// shard and the position in st_out by arithmetic, and a slot behind the end of its shard's list is empty (one partial block per
+// shard).  No queue is written, read or searched.
+// table entry of class-B block `block` (counted over all blocks of the pass): wave-uniform, scalar loads
+__device__ __forceinline__ uint32_t wf_entry_of(const PT_CONST_AS uint32_t* blkpfx, uint32_t block) {
+    uint32_t lo = (uint32_t)kWfShards, hi = 2u * (uint32_t)kWfShards;
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (blkpfx[mid] <= block) lo = mid; else hi = mid; }
     return lo;
+}
+// per lane: slot v -> position in st_out; false = empty slot.  `lo0`: a table entry at or before the slot's (the wave's cursor)
+__device__ __forceinline__ bool wf_slot(const WfArgs& A, uint32_t blocks_a, uint32_t v, uint32_t lo0, uint32_t& pos) {
+    const uint32_t b = blocks_a + (v >> 8);
+    uint32_t lo = lo0;
+    while (A.in_blkpfx[lo + 1] <= b) lo++;                 // in_blkpfx[2 kWfShards] = all blocks > b
+    const uint32_t local = (b - A.in_blkpfx[lo]) * (uint32_t)kBlock + (v & 255u);
+    pos = (lo - (uint32_t)kWfShards) * A.region + (A.region - 1u - local);      // class B grows from the back of its shard's region
+    return local < A.in_count[lo];
 }
 
 // persistent BVH walker with per-lane dynamic refill from the sharded queues
@@ -1735,12 +1746,13 @@ __device__ __forceinline__ void bvh_bind(BvhNodesLds& B, const DScene& S, int) {
 template <int LDS, int BS, bool MULTI>
 __global__ __launch_bounds__(BS, (BS == 256 ? PT_TRAV_WAVES : 4)) void wf_trav(WfArgs A) {
     const DScene& S = A.S;
-    // Work distribution over the CONCATENATED queue (virtual indices; shard s owns [trav_pfx[s], trav_pfx[s+1])):
+    // Work distribution over the slots of the class-B blocks (wf_slot above):
     // wave w owns chunk w outright, later chunks come from one shared cursor.  The static first chunk
     // matters: 8192 waves all opening with an atomicAdd on ONE word cost ~240 us per launch (same-address
     // atomics retire at ~88 / us), 2.6 ms per frame and most of the multi-rank overhead; a queue that
     // the static chunks cover never touches the cursor at all.
-    const uint32_t n_q = A.hdr[2];
+    const uint32_t blocks_a = A.in_blkpfx[kWfShards];
+    const uint32_t n_q = (A.in_blkpfx[2 * kWfShards] - blocks_a) * (uint32_t)kBlock;      // slots
     const uint32_t n_waves = gridDim.x * ((uint32_t)BS / 64u);
     // 256 rays per grab (128: the cursor's round trip shows, trav x3; 1024: long tails, +5 %).  A queue too short to give every
     // wave 256 rays is dealt out evenly instead, in whole waves' worth of 64: 200 k rays are then one walk's time on 3 k waves,
@@ -1774,9 +1786,9 @@ __global__ __launch_bounds__(BS, (BS == 256 ? PT_TRAV_WAVES : 4)) void wf_trav(W
     if (wnext >= n_q) { wnext = wend = 0; drained = true; }
     // shard of the chunk's first entry, kept wave-uniform (SGPRs): a lane then finds its own shard with a step or two
     // instead of an eight-deep chain of dependent vector loads at every refill
-    uint32_t wlo = drained ? 0u : wf_shard_of(A.trav_pfx, (uint32_t)__builtin_amdgcn_readfirstlane((int)wnext));
+    uint32_t wlo = drained ? (uint32_t)kWfShards : wf_entry_of(A.in_blkpfx, blocks_a + ((uint32_t)__builtin_amdgcn_readfirstlane((int)wnext) >> 8));
     bool have = false;
-    size_t pos = 0;
+    uint32_t pos = 0;
     f3 o = mk3(0.0f, 0.0f, 0.0f), d = o, too = o, tod = o, tinv = o;
     Best best; best.t = 0.0f; best.obj = -1; best.tri = -1; best.u = best.v = 0.0f;
     int tm = 0, ti = 0, tend = 0, ttb = 0, te2 = 0, tbtri = -1;
@@ -1800,16 +1812,12 @@ __global__ __launch_bounds__(BS, (BS == 256 ? PT_TRAV_WAVES : 4)) void wf_trav(W
                     base = (uint32_t)__shfl((int)base, 0);
                 }
                 if (base >= n_q) drained = true;
-                else { wnext = base; wend = min(base + chunk, n_q); wlo = wf_shard_of(A.trav_pfx, (uint32_t)__builtin_amdgcn_readfirstlane((int)base)); }
+                else { wnext = base; wend = min(base + chunk, n_q); wlo = wf_entry_of(A.in_blkpfx, blocks_a + ((uint32_t)__builtin_amdgcn_readfirstlane((int)base) >> 8)); }
             }
             const uint32_t avail = wend - wnext;
             const uint32_t rank = (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
-            const bool take = !have && rank < avail;
+            const bool take = !have && rank < avail && wf_slot(A, blocks_a, wnext + rank, wlo, pos);
             if (take) {
-                const uint32_t vi = wnext + rank;
-                uint32_t lo = wlo;                                   // which shard's region holds virtual index vi (>= the chunk's first)
-                while (A.trav_pfx[lo + 1] <= vi) lo++;               // trav_pfx[kWfShards] = n_q > vi
-                pos = A.trav_q[(size_t)lo * A.region + (vi - A.trav_pfx[lo])];
                 const float4 q0 = A.st_out[st_idx(0, pos, cap)], q1 = A.st_out[st_idx(1, pos, cap)];
                 const Hit2 hr = *st_hit(A.st_out, pos, cap);
                 o = mk3(q0.x, q0.y, q0.z); d = mk3(q0.w, q1.x, q1.y);
@@ -1923,7 +1931,8 @@ __global__ __launch_bounds__(BS, (BS == 256 ? PT_TRAV_WAVES : 4)) void wf_trav(W
 template <int BS, bool MULTI>
 __global__ __launch_bounds__(BS, 8) void wf_trav_i(WfArgs A) {
     const DScene& S = A.S;
-    const uint32_t n_q = A.hdr[2];
+    const uint32_t blocks_a = A.in_blkpfx[kWfShards];
+    const uint32_t n_q = (A.in_blkpfx[2 * kWfShards] - blocks_a) * (uint32_t)kBlock;      // slots of the class-B blocks (wf_slot)
     const uint32_t n_waves = gridDim.x * ((uint32_t)BS / 64u);
     uint32_t chunk = 256u;                                           // as wf_trav
     if (n_q < n_waves * 256u) chunk = max(64u, ((n_q + n_waves - 1u) / n_waves + 63u) & ~63u);
@@ -1946,9 +1955,9 @@ __global__ __launch_bounds__(BS, 8) void wf_trav_i(WfArgs A) {
     uint32_t wnext = wave_id * chunk, wend = min(wnext + chunk, n_q);
     bool drained = false;
     if (wnext >= n_q) { wnext = wend = 0; drained = true; }
-    uint32_t wlo = drained ? 0u : wf_shard_of(A.trav_pfx, (uint32_t)__builtin_amdgcn_readfirstlane((int)wnext));
+    uint32_t wlo = drained ? (uint32_t)kWfShards : wf_entry_of(A.in_blkpfx, blocks_a + ((uint32_t)__builtin_amdgcn_readfirstlane((int)wnext) >> 8));
     bool have = false;
-    size_t pos = 0;
+    uint32_t pos = 0;
     f3 o = mk3(0.0f, 0.0f, 0.0f), d = o, too = o, tod = o, tinv = o;
     Best best; best.t = 0.0f; best.obj = -1; best.tri = -1; best.u = best.v = 0.0f;
     int tm = 0, id = kIdEnd, tbtri = -1;                             // id: the node the lane stands on (>= 0 interior: c0, c1 hold it)
@@ -1976,16 +1985,12 @@ __global__ __launch_bounds__(BS, 8) void wf_trav_i(WfArgs A) {
                     base = (uint32_t)__shfl((int)base, 0);
                 }
                 if (base >= n_q) drained = true;
-                else { wnext = base; wend = min(base + chunk, n_q); wlo = wf_shard_of(A.trav_pfx, (uint32_t)__builtin_amdgcn_readfirstlane((int)base)); }
+                else { wnext = base; wend = min(base + chunk, n_q); wlo = wf_entry_of(A.in_blkpfx, blocks_a + ((uint32_t)__builtin_amdgcn_readfirstlane((int)base) >> 8)); }
             }
             const uint32_t avail = wend - wnext;
             const uint32_t rank = (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
-            const bool take = !have && rank < avail;
+            const bool take = !have && rank < avail && wf_slot(A, blocks_a, wnext + rank, wlo, pos);
             if (take) {
-                const uint32_t vi = wnext + rank;
-                uint32_t lo = wlo;
-                while (A.trav_pfx[lo + 1] <= vi) lo++;
-                pos = A.trav_q[(size_t)lo * A.region + (vi - A.trav_pfx[lo])];
                 const float4 q0 = A.st_out[st_idx(0, pos, cap)], q1 = A.st_out[st_idx(1, pos, cap)];
                 const Hit2 hr = *st_hit(A.st_out, pos, cap);
                 o = mk3(q0.x, q0.y, q0.z); d = mk3(q0.w, q1.x, q1.y);
@@ -1995,7 +2000,7 @@ __global__ __launch_bounds__(BS, 8) void wf_trav_i(WfArgs A) {
                 if (enter_next_mesh(S, B, tm, o, d, t_min, t_max, too, tod, tinv, ti, tend, ttb, MULTI ? A.trav_mask : 1u) && (MULTI || tm == 0)) { start_mesh(); have = true; }
             }
             wnext += min(avail, n_idle);
-            if (wnext < wend) { const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)wnext); while (A.trav_pfx[wlo + 1] <= w) wlo++; }
+            if (wnext < wend) { const uint32_t wb = blocks_a + ((uint32_t)__builtin_amdgcn_readfirstlane((int)wnext) >> 8); while (A.in_blkpfx[wlo + 1] <= wb) wlo++; }
         }
         if (__builtin_amdgcn_ballot_w64(have) == 0ull) {
             if (drained) break;
@@ -2159,7 +2164,7 @@ __global__ __launch_bounds__(256) void wf_filter_f(WfArgs A) {
     const float t_min = 0.001f, t_max = A.C.max_trace_dist;
     const uint32_t cap = A.cap;
     const uint32_t shard = blockIdx.x % (uint32_t)kWfShards, sub = blockIdx.x / (uint32_t)kWfShards, n_sub = gridDim.x / (uint32_t)kWfShards;
-    const uint32_t count = A.trav_pfx[shard + 1] - A.trav_pfx[shard];
+    const uint32_t count = A.in_count[(uint32_t)kWfShards + shard];            // this shard's class-B paths = its rays that wait for a mesh walk
     const uint32_t lane = threadIdx.x & 63u;
     // The kept entries are staged in LDS and leave in runs of >= 1024 behind ONE atomic on the list's counter (a single address
     // retires ~90 atomics per microsecond: one per wave and 64 entries took 29 ms here)
@@ -2181,7 +2186,7 @@ __global__ __launch_bounds__(256) void wf_filter_f(WfArgs A) {
         uint32_t pos = 0;
         bool keep = false;
         if (k < count) {
-            pos = A.trav_q[(size_t)shard * A.region + k];
+            pos = shard * A.region + (A.region - 1u - k);
             const float4 q0 = A.st_out[st_idx(0, pos, cap)], q1 = A.st_out[st_idx(1, pos, cap)];
             keep = enters_two_stage_root(S, A.trav_mask, mk3(q0.x, q0.y, q0.z), mk3(q0.w, q1.x, q1.y), t_min, t_max);
         }
@@ -2500,9 +2505,9 @@ __global__ __launch_bounds__(256) void wf_prefix(uint32_t* __restrict__ out_coun
     const uint32_t t = threadIdx.x;
     if (t == 0) tot_b = 0;
     __syncthreads();
-    const uint32_t a = out_count[t], b = out_count[kWfShards + t], q = trav_count[t];
+    const uint32_t a = out_count[t], b = out_count[kWfShards + t], q = b;   // the rays that wait for a mesh walk = the class-B paths
     atomicAdd(&tot_b, b);
-    out_count[t] = 0; out_count[kWfShards + t] = 0; trav_count[t] = 0;       // ready for the next wf_main
+    out_count[t] = 0; out_count[kWfShards + t] = 0;                         // ready for the next wf_main
     if (t < 4) trav_count[kWfShards + t] = 0;                               // trav_head[0] / [1]: the shared cursors of wf_trav / wf_trav_f; [2]: wf_filter_f's count
     in_count[t] = a; in_count[kWfShards + t] = b;
     const uint32_t va = (a + kBlock - 1) / kBlock, vb = (b + kBlock - 1) / kBlock;
