@@ -186,11 +186,11 @@ typedef struct mi_render_opts {
     int32_t  variant;           /* 0 = default kernel; see mi_variant                    */
     int32_t  want_signature;    /* 1 = also produce per-pixel path signatures (diagnostic) */
     uint32_t flags;             /* MI_OPT_* bits, 0 = defaults                           */
-    uint64_t max_state_bytes;   /* wavefront pipeline: upper bound on the HBM it may hold for path state, queues and
-                                 * sample slots (0 = 60 % of the free HBM: a whole 1080p/256 spp frame is one 112 GB
+    uint64_t max_state_bytes;   /* wavefront pipeline: upper bound on the HBM it may hold for path state and
+                                 * sample slots (0 = 60 % of the free HBM: a whole 1080p/256 spp frame is one 110 GB
                                  * batch).  A smaller budget means more, smaller sample batches: same image, bit for
                                  * bit, lower throughput (256 M / 64 M / 16 M paths per batch: 161 / 187 / 257 ms on cfg2).
-                                 * The smallest batch is one sample of every pixel of the rank (about 220 B per pixel, 290 B
+                                 * The smallest batch is one sample of every pixel of the rank (about 210 B per pixel, 280 B
                                  * with a two-stage mesh): a non-zero budget below that is MI_ERR_INVALID, never silently exceeded */
 } mi_render_opts;               /* 32 bytes */
 
@@ -280,9 +280,9 @@ int  mi_tonemap_device(mi_ctx* ctx, const mi_camera_desc* cam,
  * launch stream); synchronises on the stop event. */
 int  mi_last_kernel_ms(mi_ctx* ctx, float* ms);
 
-/* Size and allocate the wavefront pipeline's HBM buffers (path state, queue, sample slots) for
+/* Size and allocate the wavefront pipeline's HBM buffers (path state, sample slots) for
  * this camera with the image shared by `world` ranks, so that the first render does not pay the
- * allocation (about 112 GB for a whole 1080p / 256 spp frame on one GPU).  `max_state_bytes` as in
+ * allocation (about 110 GB for a whole 1080p / 256 spp frame on one GPU).  `max_state_bytes` as in
  * mi_render_opts (0 = 60 % of the free HBM).  Optional. */
 int  mi_reserve(mi_ctx* ctx, const mi_camera_desc* cam, int32_t world, uint64_t max_state_bytes);
 
@@ -296,7 +296,7 @@ int  mi_last_pipeline_ms(mi_ctx* ctx, float* out8);
 
 /* Path counts of the most recent wavefront render, for traffic accounting: out8 = { passes (wf_main launches
  * that left survivors or ended the batch), class-A paths written to (and read back from) the HBM path state summed
- * over the passes, class-B paths likewise, traversal-queue entries, sample slots, compact pixels, 0, 0 }.
+ * over the passes, class-B paths likewise, rays that waited for a mesh walk (= the class-B paths: the walkers read those lists, there is no queue), sample slots, compact pixels, 0, 0 }.
  * The bytes these stand for (72 B per class-A path and direction, 76 B per class-B path, ...) are in DESIGN.md. */
 int  mi_last_pipeline_counts(mi_ctx* ctx, uint64_t* out8);
 
