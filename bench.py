@@ -100,8 +100,8 @@ def committed_pmc(cfg: str):
 
 def traffic_model(counts, n_meshes):
     """HBM bytes of one pipeline pass from this run's own path counts: every path that
-    survives a pass is written once and read once (72 B class A, 76 B class B), a ray that waits for a mesh walk (= a
-    class-B path; there is no queue) costs the walker's fetch of origin, direction and hit record (40 B), every sample
+    survives a pass is written once and read once (72 B class A, 76 B class B), a class-B path (the walkers' work list;
+    there is no queue) costs the walker's fetch of origin, direction and hit record (40 B), every sample
     slot is written once and read once by wf_reduce (16 B each), and the frame leaves as 16 B accumulator +
     12 B compact pixel.  An upper bound: the samples of dead tiles are neither written nor read."""
     state = 2 * (counts["paths_a"] * 72 + counts["paths_b"] * 76)

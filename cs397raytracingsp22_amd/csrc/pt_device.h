@@ -258,7 +258,7 @@ struct WfArgs {
     uint32_t* trav_count; // [kWfShards] unused since the walkers take the class-B blocks directly (wf_slot); trav_head sits behind it
     uint32_t* trav_head;  // [0]: consumption head over the CONCATENATED per-shard queues (wf_trav grabs 256 entries per atomic); [1]: the same for wf_trav_f
     const PT_CONST_AS uint32_t* trav_pfx;   // [kWfShards + 1] exclusive prefix of the class-B counts (statistics)
-    const PT_CONST_AS uint32_t* hdr;   // [4] written by wf_prefix after every wf_main: blocks of the next pass, live paths, rays waiting for a mesh walk (= class-B paths)
+    const PT_CONST_AS uint32_t* hdr;   // [4] written by wf_prefix after every wf_main: blocks of the next pass, live paths, class-B paths (the walkers' work list)
     float4* samp;         // [s_count][npix] finished samples: L.xyz, signature bits
     float4* accum;        // [npix] running per-pixel sum (xyz) and signature sum (w bits)
     float*    out;        // compact framebuffer [tiles_padded][1024][3]

@@ -1667,8 +1667,9 @@ __global__ __launch_bounds__(kBlock, (MESH == 2 ? PT_MAIN_WAVES : (MESH == 1 ? P
     const bool cls_b2 = alive && !cls_a;
     // The two wave-aggregated appends (class A, class B) go out as ONE vector atomic with lanes 0 and 1 addressing the two
     // counters: one round trip per wave instead of two in a row (a returning atomic takes ~3k cycles with every CU issuing
-    // them; hipcc waits after each one).  There is no traversal queue: class B IS the set of rays that wait for a mesh walk
-    // (alive && enters — best.tri is still -1 here), and the walkers go through the class-B blocks of the next pass' table.
+    // them; hipcc waits after each one).  There is no traversal queue: every ray that waits for a mesh walk is a class-B path
+    // (class B = enters, or a Sphere / ConvexVolume hit pending), and the walkers go through the class-B blocks of the next
+    // pass' table; a class-B path that entered no root fails the walker's root tests as it failed them here (same arithmetic).
     uint32_t ia, ib;
     {
         const unsigned long long ma = __builtin_amdgcn_ballot_w64(cls_a), mb = __builtin_amdgcn_ballot_w64(cls_b2);
@@ -1704,11 +1705,13 @@ __global__ __launch_bounds__(kBlock, (MESH == 2 ? PT_MAIN_WAVES : (MESH == 1 ? P
 #endif
 }
 
-// The walkers' work list.  The rays that wait for a mesh walk are exactly the class-B paths of the pass' output, and wf_prefix
-// has just tabulated those for the next wf_main (in_count / in_blkpfx, entries kWfShards .. 2 kWfShards - 1: per shard, whole
-// blocks of 256).  So the walkers take SLOTS: slot v = lane v % 256 of class-B block v / 256; the block's table entry gives the
-// shard and the position in st_out by arithmetic, and a slot behind the end of its shard's list is empty (one partial block per
-// shard).  No queue is written, read or searched.
+// The walkers' work list.  Every ray that waits for a mesh walk is a class-B path of the pass' output, and wf_prefix has just
+// tabulated those for the next wf_main (in_count / in_blkpfx, entries kWfShards .. 2 kWfShards - 1: per shard, whole blocks of
+// 256).  So the walkers take SLOTS: slot v = lane v % 256 of class-B block v / 256; the block's table entry gives the shard and
+// the position in st_out by arithmetic, and a slot behind the end of its shard's list is empty (one partial block per shard).
+// No queue is written, read or searched.  Class B also holds the paths whose pending hit is a Sphere or a ConvexVolume and whose
+// ray entered no mesh root (cfg2: 5.6 % of class B, HEAD: 12 %): a walker's refill rejects them by the root tests wf_main ran
+// on them already — a wasted slot, no wasted instruction (the test runs for the whole refill group anyway).
 // table entry of class-B block `block` (counted over all blocks of the pass): wave-uniform, scalar loads
 __device__ __forceinline__ uint32_t wf_entry_of(const PT_CONST_AS uint32_t* blkpfx, uint32_t block) {
     uint32_t lo = (uint32_t)kWfShards, hi = 2u * (uint32_t)kWfShards;
@@ -2164,7 +2167,7 @@ __global__ __launch_bounds__(256) void wf_filter_f(WfArgs A) {
     const float t_min = 0.001f, t_max = A.C.max_trace_dist;
     const uint32_t cap = A.cap;
     const uint32_t shard = blockIdx.x % (uint32_t)kWfShards, sub = blockIdx.x / (uint32_t)kWfShards, n_sub = gridDim.x / (uint32_t)kWfShards;
-    const uint32_t count = A.in_count[(uint32_t)kWfShards + shard];            // this shard's class-B paths = its rays that wait for a mesh walk
+    const uint32_t count = A.in_count[(uint32_t)kWfShards + shard];            // this shard's class-B paths: its rays that wait for a mesh walk are among them
     const uint32_t lane = threadIdx.x & 63u;
     // The kept entries are staged in LDS and leave in runs of >= 1024 behind ONE atomic on the list's counter (a single address
     // retires ~90 atomics per microsecond: one per wave and 64 entries took 29 ms here)
@@ -2505,7 +2508,7 @@ __global__ __launch_bounds__(256) void wf_prefix(uint32_t* __restrict__ out_coun
     const uint32_t t = threadIdx.x;
     if (t == 0) tot_b = 0;
     __syncthreads();
-    const uint32_t a = out_count[t], b = out_count[kWfShards + t], q = b;   // the rays that wait for a mesh walk = the class-B paths
+    const uint32_t a = out_count[t], b = out_count[kWfShards + t], q = b;   // the walkers' work list = the class-B paths
     atomicAdd(&tot_b, b);
     out_count[t] = 0; out_count[kWfShards + t] = 0;                         // ready for the next wf_main
     if (t < 4) trav_count[kWfShards + t] = 0;                               // trav_head[0] / [1]: the shared cursors of wf_trav / wf_trav_f; [2]: wf_filter_f's count

@@ -13,6 +13,7 @@
 //         fixed-point YCbCr -> RGB — so the result equals libjpeg's (PIL's) bit for bit on the reference's files; the `image`
 //         crate's jpeg-decoder 0.1.22 is a different implementation of the same standard and may differ from both by +-1-2 LSB
 //         (SURVEY.md section 8c says so and ships textures pre-decoded for parity runs).
+//   BMP / GIF / TIFF  the common sub-formats: texture_formats.hpp
 // Not decoded (nullopt): 16-bit PNG channels (the crate's 16 -> 8 bit conversion could not be pinned without its source),
 // arithmetic-coded / lossless / 12-bit / CMYK JPEG, exotic sampling factors.
 #pragma once
@@ -23,6 +24,8 @@
 #include <string>
 #include <vector>
 #include <zlib.h>
+
+#include "texture_formats.hpp"
 
 namespace cs397 {
 
@@ -43,6 +46,17 @@ struct Texture {                                       // texture.rs:12-14
         if (d.size() >= 8 && memcmp(d.data(), png_sig, 8) == 0) return decode_png(d);
         if (d.size() >= 2 && d[0] == 'P' && d[1] == '6') return decode_ppm(d);
         if (d.size() >= 2 && d[0] == 0xff && d[1] == 0xd8) return decode_jpeg(d);
+        {   // the rarer containers image::open reads as well (texture_formats.hpp)
+            const bool bmp = d.size() >= 2 && d[0] == 'B' && d[1] == 'M', gif = d.size() >= 4 && memcmp(d.data(), "GIF8", 4) == 0;
+            const bool tiff = d.size() >= 4 && (memcmp(d.data(), "II*\0", 4) == 0 || memcmp(d.data(), "MM\0*", 4) == 0);
+            if (bmp || gif || tiff) {
+                Texture t;
+                const bool ok = bmp ? formats::decode_bmp(d, t.width, t.height, t.rgb) : gif ? formats::decode_gif(d, t.width, t.height, t.rgb)
+                                                                                                : formats::decode_tiff(d, t.width, t.height, t.rgb);
+                if (ok) return t;
+                return std::nullopt;
+            }
+        }
         return decode_tga(d);                                                            // TGA has no magic: try it last
     }
 

@@ -296,7 +296,7 @@ int  mi_last_pipeline_ms(mi_ctx* ctx, float* out8);
 
 /* Path counts of the most recent wavefront render, for traffic accounting: out8 = { passes (wf_main launches
  * that left survivors or ended the batch), class-A paths written to (and read back from) the HBM path state summed
- * over the passes, class-B paths likewise, rays that waited for a mesh walk (= the class-B paths: the walkers read those lists, there is no queue), sample slots, compact pixels, 0, 0 }.
+ * over the passes, class-B paths likewise, slots the mesh walkers went through (= the class-B paths: the walkers read those lists, there is no queue), sample slots, compact pixels, 0, 0 }.
  * The bytes these stand for (72 B per class-A path and direction, 76 B per class-B path, ...) are in DESIGN.md. */
 int  mi_last_pipeline_counts(mi_ctx* ctx, uint64_t* out8);
 

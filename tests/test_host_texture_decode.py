@@ -223,3 +223,151 @@ def test_hostile_headers_are_refused_without_allocating_or_overreading(decoder_a
         r = subprocess.run([decoder_asan, str(p), str(out)], capture_output=True, text=True,
                            env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1:max_allocation_size_mb=512"))
         assert r.returncode == 3, (name, r.returncode, r.stderr[-800:])   # 3 = nullopt (None); anything else is a crash or a decode
+
+
+# ---------------------------------------------------------------- BMP / GIF / TIFF (host/texture_formats.hpp)
+def save_bytes(im, fmt, **kw):
+    import io
+    b = io.BytesIO()
+    im.save(b, fmt, **kw)
+    return b.getvalue()
+
+
+@pytest.mark.parametrize("mode", ["RGB", "RGBA", "L", "P", "1"])
+@pytest.mark.parametrize("size", [(1, 1), (7, 5), (33, 18), (64, 64)])
+def test_bmp_variants(decoder, tmp_path, mode, size):
+    im = synthetic(hash((mode, size)) % 1000, size[0], size[1], mode if mode != "1" else "L")
+    if mode == "1":
+        im = im.convert("1")
+    p = tmp_path / "t.bmp"
+    p.write_bytes(save_bytes(im, "BMP"))
+    assert np.array_equal(decode(decoder, p, tmp_path), pil_rgb(p)), (mode, size)
+
+
+def test_bmp_top_down_4bit_and_rle8(decoder, tmp_path):
+    import struct
+    w, h = 13, 9
+    rng = np.random.default_rng(5)
+    idx = rng.integers(0, 16, size=(h, w), dtype=np.uint8)
+    pal = rng.integers(0, 256, size=(16, 3), dtype=np.uint8)
+
+    def bmp(bpp, comp, height_field, body, ncol):
+        off = 14 + 40 + 4 * ncol
+        hdr = b"BM" + struct.pack("<IHHI", off + len(body), 0, 0, off)
+        dib = struct.pack("<IiiHHIIiiII", 40, w, height_field, 1, bpp, comp, len(body), 2835, 2835, ncol, 0)
+        table = b"".join(bytes([int(c[2]), int(c[1]), int(c[0]), 0]) for c in pal[:ncol])
+        return hdr + dib + table + body
+    want = pal[idx]
+    # 4 bpp, top-down (negative height): rows in order, two pixels per byte, padded to 4 bytes
+    rows = []
+    for y in range(h):
+        r = bytearray((w + 1) // 2)
+        for x in range(w):
+            r[x >> 1] |= int(idx[y, x]) << (0 if x & 1 else 4)
+        rows.append(bytes(r) + b"\0" * (-len(r) % 4))
+    p = tmp_path / "td4.bmp"
+    p.write_bytes(bmp(4, 0, -h, b"".join(rows), 16))
+    assert np.array_equal(decode(decoder, p, tmp_path), want)
+    assert np.array_equal(pil_rgb(p), want)                                   # PIL reads the hand-made file the same way
+    # RLE8, bottom-up: every row as one absolute run (odd length: padded) or encoded runs, end-of-line, end-of-bitmap
+    body = bytearray()
+    for y in range(h - 1, -1, -1):
+        row = [int(v) for v in idx[y]]
+        if y % 2:
+            body += bytes([0, w]) + bytes(row) + (b"\0" if w & 1 else b"")     # absolute mode
+        else:
+            x = 0
+            while x < w:
+                n = 1
+                while x + n < w and row[x + n] == row[x]:
+                    n += 1
+                body += bytes([n, row[x]])
+                x += n
+        body += b"\0\0"
+    body += b"\0\1"
+    p = tmp_path / "rle8.bmp"
+    p.write_bytes(bmp(8, 1, h, bytes(body), 16))
+    assert np.array_equal(decode(decoder, p, tmp_path), want)
+    assert np.array_equal(pil_rgb(p), want)
+
+
+@pytest.mark.parametrize("size", [(1, 1), (9, 7), (40, 31), (128, 96)])
+@pytest.mark.parametrize("kw", [{}, {"interlace": True}, {"transparency": 3}])
+def test_gif_variants(decoder, tmp_path, size, kw):
+    im = synthetic(size[0] + len(kw), size[0], size[1], "P")
+    p = tmp_path / "t.gif"
+    p.write_bytes(save_bytes(im, "GIF", **kw))
+    assert np.array_equal(decode(decoder, p, tmp_path), pil_rgb(p)), (size, kw)
+    rgb = synthetic(3, size[0], size[1], "RGB")                                # PIL quantises to an adaptive palette on save
+    p.write_bytes(save_bytes(rgb, "GIF"))
+    assert np.array_equal(decode(decoder, p, tmp_path), pil_rgb(p))
+
+
+@pytest.mark.parametrize("mode", ["RGB", "RGBA", "L", "P"])
+@pytest.mark.parametrize("comp", [None, "packbits", "tiff_lzw", "tiff_adobe_deflate"])
+def test_tiff_variants(decoder, tmp_path, mode, comp):
+    for size in ((1, 1), (11, 6), (70, 45), (300, 200)):
+        im = synthetic(7 + size[0], size[0], size[1], mode)
+        p = tmp_path / "t.tif"
+        kw = {} if comp is None else {"compression": comp}
+        p.write_bytes(save_bytes(im, "TIFF", **kw))
+        assert np.array_equal(decode(decoder, p, tmp_path), pil_rgb(p)), (mode, comp, size)
+    if comp in ("tiff_lzw", "tiff_adobe_deflate") and mode in ("RGB", "L"):
+        p.write_bytes(save_bytes(im, "TIFF", compression=comp, tiffinfo={317: 2}))     # horizontal predictor
+        assert np.array_equal(decode(decoder, p, tmp_path), pil_rgb(p)), (mode, comp, "predictor")
+
+
+def test_tiff_big_endian_and_white_is_zero(decoder, tmp_path):
+    import struct
+    w, h = 6, 4
+    px = np.arange(w * h, dtype=np.uint8).reshape(h, w) * 9
+    ent = [(256, 3, 1, w), (257, 3, 1, h), (258, 3, 1, 8), (259, 3, 1, 1), (262, 3, 1, 0), (273, 4, 1, 8), (277, 3, 1, 1), (278, 3, 1, h),
+           (279, 4, 1, w * h)]
+    ifd_off = 8 + w * h
+    ifd = struct.pack(">H", len(ent))
+    for tag, typ, cnt, val in ent:
+        ifd += struct.pack(">HHI", tag, typ, cnt) + (struct.pack(">HH", val, 0) if typ == 3 else struct.pack(">I", val))
+    ifd += struct.pack(">I", 0)
+    p = tmp_path / "mm.tif"
+    p.write_bytes(b"MM\x00\x2a" + struct.pack(">I", ifd_off) + px.tobytes() + ifd)
+    want = np.repeat((255 - px)[:, :, None], 3, axis=2)
+    assert np.array_equal(decode(decoder, p, tmp_path), want)
+    assert np.array_equal(pil_rgb(p), want)
+
+
+def test_hostile_bmp_gif_tiff_headers_are_refused(decoder_asan, tmp_path):
+    import struct
+    cases = {}
+    good = save_bytes(synthetic(2, 16, 16, "RGB"), "BMP")
+    b = bytearray(good); b[18:22] = struct.pack("<i", 20000); b[22:26] = struct.pack("<i", 6000)
+    cases["huge.bmp"] = bytes(b)
+    b = bytearray(good); b[10:14] = struct.pack("<I", 1 << 30)
+    cases["offset.bmp"] = bytes(b)
+    cases["cut.bmp"] = good[:40]
+    p8 = bytearray(save_bytes(synthetic(2, 16, 16, "P"), "BMP")); p8[30:34] = struct.pack("<I", 1); p8[18:22] = struct.pack("<i", 16000); p8[22:26] = struct.pack("<i", 8000)
+    cases["huge_rle.bmp"] = bytes(p8)
+    g = bytearray(save_bytes(synthetic(2, 16, 16, "P"), "GIF"))
+    cases["cut.gif"] = bytes(g[:len(g) // 2])
+    g2 = bytearray(g); g2[6:8] = struct.pack("<H", 16000); g2[8:10] = struct.pack("<H", 8000)
+    k = g2.index(b"\x2c"); g2[k + 5:k + 7] = struct.pack("<H", 16000); g2[k + 7:k + 9] = struct.pack("<H", 8000)
+    cases["huge.gif"] = bytes(g2)
+    t = bytearray(save_bytes(synthetic(2, 16, 16, "RGB"), "TIFF", compression="tiff_lzw"))
+    cases["cut.tif"] = bytes(t[:len(t) - 40])
+    ifd = struct.unpack("<I", t[4:8])[0]
+    n = struct.unpack("<H", t[ifd:ifd + 2])[0]
+    t2 = bytearray(t)
+    for e in range(n):
+        o = ifd + 2 + 12 * e
+        tag = struct.unpack("<H", t2[o:o + 2])[0]
+        if tag in (256, 257, 278):
+            typ = struct.unpack("<H", t2[o + 2:o + 4])[0]
+            t2[o + 8:o + 12] = struct.pack("<HH", 9000, 0) if typ == 3 else struct.pack("<I", 9000)
+    cases["huge.tif"] = bytes(t2)
+    cases["loop.tif"] = b"II*\x00" + struct.pack("<I", 0xfffffff0)
+    for name, data in cases.items():
+        p = tmp_path / name
+        p.write_bytes(data)
+        out = tmp_path / "o.raw"
+        r = subprocess.run([decoder_asan, str(p), str(out)], capture_output=True, text=True,
+                           env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1:max_allocation_size_mb=512"))
+        assert r.returncode == 3, (name, r.returncode, r.stderr[-800:])
