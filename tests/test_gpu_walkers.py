@@ -92,3 +92,24 @@ def test_pass_schedules_agree_with_the_oracle(orc, scene):
         assert int((sig != rsig).sum()) == 0, f"{env}: paths differ from the oracle"
         ref = f32 if ref is None else ref
         assert np.array_equal(f32, ref), env
+
+
+@pytest.mark.parametrize("mode", [0, 2, 3, 4])
+def test_axis_aligned_rays_through_meshes(orc, mode):
+    """Rays with exactly zero direction components: 1/d is infinite on two axes and the slab test meets NaN products (0 * inf) at
+    box planes through the ray, which the reference's f32::max / min drop (geometry.rs:59-76).  An orthographic camera along -z
+    sends every camera ray with d = (0, 0, -1) into meshes that are only translated, so object space sees the same direction; a
+    mirror cube reflects some of them straight back.  (Written for an experimental v_med3 form of the walkers' box test, which
+    needs another form for exactly these rays — tools/experiments/r03_walker_med3_slab.diff; kept as a parity case of its own.)"""
+    from test_oracle_kat import cube_mesh
+    from cs397raytracingsp22_amd import Metal
+    sc = scenes.config2(96, 64, 8, 6)
+    sc.camera.projection_mode = abi.MI_PROJ_ORTHOGRAPHIC
+    sc.camera.view_dir = (0.0, 0.0, -1.0)
+    grey = Lambertian(albedo=(0.7, 0.7, 0.7))
+    sc.objects.append(StaticMesh(cube_mesh(-0.5, 0.5), grey, [None] * 5, cgmath.from_translation((0.0, 2.0, 0.5))))
+    sc.objects.append(StaticMesh(cube_mesh(-0.25, 0.25), Metal(albedo=(0.9, 0.9, 0.9), roughness=0.0), [None] * 5, cgmath.from_translation((0.5, 2.0, 1.5))))
+    flat = sc.flatten()
+    _, _, rsig, _ = orc.OracleScene(flat).render(sc.camera, seed=21)
+    _, sig = render_with_mode(mode, flat, sc.camera, 21)
+    assert int((sig != rsig).sum()) == 0, f"walker mode {mode}: paths differ from the oracle"
