@@ -78,6 +78,9 @@
 #define PT_TRAVI_LEAF2 16   // wf_trav_i: a leaf step tests a second triangle when at least this many lanes sit on a leaf again
 #endif
 #ifndef PT_MIN_WAVES
+#ifndef PT_TRAV_PEND
+#define PT_TRAV_PEND 16    // walkers over several meshes: lanes that have finished one mesh wait until this many can take the next root tests together (HEAD walker: 4 / 8 / 16 / 24 -> 40.9 / 38.1 / 36.3 / 37.0 ms; on the spot: 43.4)
+#endif
 #define PT_MIN_WAVES 4      // waves per SIMD the register allocator must leave room for (<= 128 VGPRs)
 #endif
 
@@ -1855,7 +1858,8 @@ __global__ __launch_bounds__(BS, (BS == 256 ? PT_TRAV_WAVES : 4)) void wf_trav(W
         // wf_trav 35.6 -> 43.5 ms on cfg2, 81 -> 96 ms on cfg4: 74 instead of 64 VGPRs (6 instead of 8 waves per SIMD),
         // 20 % more instructions per node step, and every hit replays part of the walk.)
         const int tri = __float_as_int(c1.w);
-        const bool at_leaf = have & (tri >= 0), at_inner = have & (tri < 0);
+        const bool walking = have & (!MULTI | (ti < tend));             // MULTI: a lane that has finished a mesh may be waiting for company (below)
+        const bool at_leaf = walking & (tri >= 0), at_inner = walking & (tri < 0);
         const int n_leaf = __popcll(__builtin_amdgcn_ballot_w64(at_leaf));
         const int n_inner = __popcll(__builtin_amdgcn_ballot_w64(at_inner));
         if (n_inner >= n_leaf * PT_TRAV_LEAF_W) {
@@ -1896,23 +1900,27 @@ __global__ __launch_bounds__(BS, (BS == 256 ? PT_TRAV_WAVES : 4)) void wf_trav(W
 #ifdef PT_TRAV_DIAG
         if (n_inner < n_leaf) { dg_lsteps++; dg_llanes += (unsigned long long)n_leaf; }
 #endif
-        if (have && ti >= tend) {
-            if (tbtri >= 0) consider(best, tbt, S.meshes[tm].object_index, tbtri, tbu, tbv);
-            tm++;
-            if (MULTI && enter_next_mesh(S, B, tm, o, d, t_min, t_max, too, tod, tinv, ti, tend, ttb, A.trav_mask)) {
-                tbt = t_max; tbtri = -1; tbu = tbv = 0.0f;
-                te2 = S.meshes[tm].e2_begin;
-                B.node(ti, c0, c1);
-            } else {
-                // StaticMesh results merged: hand the closest hit back to the path.  70 % of the rays that enter
-                // a root box hit no triangle closer than the list's hit: their record is already right.
-                if (best.tri >= 0) {
-                    Hit2 hw; hw.t = best.t; hw.obj = best.obj;
-                    *st_hit(A.st_out, pos, cap) = hw;                 // the signature has its own words: no read-modify-write
-                    *st_tri(A.st_out, pos, cap) = best.tri;
-                    A.st_out[st_idx(5, pos, cap)] = make_float4(best.u, best.v, 0.0f, 0.0f);
+        // MULTI: the root tests of a further mesh wait until PT_TRAV_PEND lanes need them, or nobody is walking (see wf_trav_i)
+        const bool ended = have && ti >= tend;
+        if (MULTI ? (__popcll(__builtin_amdgcn_ballot_w64(ended)) >= PT_TRAV_PEND || __builtin_amdgcn_ballot_w64(have & (ti < tend)) == 0ull) : true) {
+            if (ended) {
+                if (tbtri >= 0) consider(best, tbt, S.meshes[tm].object_index, tbtri, tbu, tbv);
+                tm++;
+                if (MULTI && enter_next_mesh(S, B, tm, o, d, t_min, t_max, too, tod, tinv, ti, tend, ttb, A.trav_mask)) {
+                    tbt = t_max; tbtri = -1; tbu = tbv = 0.0f;
+                    te2 = S.meshes[tm].e2_begin;
+                    B.node(ti, c0, c1);
+                } else {
+                    // StaticMesh results merged: hand the closest hit back to the path.  70 % of the rays that enter
+                    // a root box hit no triangle closer than the list's hit: their record is already right.
+                    if (best.tri >= 0) {
+                        Hit2 hw; hw.t = best.t; hw.obj = best.obj;
+                        *st_hit(A.st_out, pos, cap) = hw;                 // the signature has its own words: no read-modify-write
+                        *st_tri(A.st_out, pos, cap) = best.tri;
+                        A.st_out[st_idx(5, pos, cap)] = make_float4(best.u, best.v, 0.0f, 0.0f);
+                    }
+                    have = false;
                 }
-                have = false;
             }
         }
     }
@@ -2038,20 +2046,26 @@ __global__ __launch_bounds__(BS, 8) void wf_trav_i(WfArgs A) {
                 }
             }
         }
-        if (have && id == kIdEnd) {
-            // this mesh is done: StaticMesh::intersect_ray returns (geometry.rs:305-313)
-            if (tbtri >= 0) consider(best, tbt, S.meshes[tm].object_index, tbtri, tbu, tbv);
-            tm++;
-            int ti, tend, ttb;
-            if (MULTI && enter_next_mesh(S, B, tm, o, d, t_min, t_max, too, tod, tinv, ti, tend, ttb, A.trav_mask)) start_mesh();
-            else {
-                if (best.tri >= 0) {
-                    Hit2 hw; hw.t = best.t; hw.obj = best.obj;
-                    *st_hit(A.st_out, pos, cap) = hw;
-                    *st_tri(A.st_out, pos, cap) = best.tri;
-                    A.st_out[st_idx(5, pos, cap)] = make_float4(best.u, best.v, 0.0f, 0.0f);
+        // this mesh is done: StaticMesh::intersect_ray returns (geometry.rs:305-313).  MULTI: the root tests of a further mesh are ~120
+        // instructions; run on the spot they serve the one or two lanes that finish in this very step, every other step.  So a lane
+        // that finishes a mesh only notes it (id stays kIdEnd, the lane sits out the steps), and the entry tests run once
+        // PT_TRAV_PEND lanes wait for one — or nobody is walking any more.
+        const bool ended = have && id == kIdEnd;
+        if (MULTI ? (__popcll(__builtin_amdgcn_ballot_w64(ended)) >= PT_TRAV_PEND || __builtin_amdgcn_ballot_w64(have & (id != kIdEnd)) == 0ull) : true) {
+            if (ended) {
+                if (tbtri >= 0) consider(best, tbt, S.meshes[tm].object_index, tbtri, tbu, tbv);
+                tm++;
+                int ti, tend, ttb;
+                if (MULTI && enter_next_mesh(S, B, tm, o, d, t_min, t_max, too, tod, tinv, ti, tend, ttb, A.trav_mask)) start_mesh();
+                else {
+                    if (best.tri >= 0) {
+                        Hit2 hw; hw.t = best.t; hw.obj = best.obj;
+                        *st_hit(A.st_out, pos, cap) = hw;
+                        *st_tri(A.st_out, pos, cap) = best.tri;
+                        A.st_out[st_idx(5, pos, cap)] = make_float4(best.u, best.v, 0.0f, 0.0f);
+                    }
+                    have = false;
                 }
-                have = false;
             }
         }
     }
