@@ -1800,6 +1800,15 @@ __global__ __launch_bounds__(BS, (BS == 256 ? PT_TRAV_WAVES : 4)) void wf_trav(W
     int tm = 0, ti = 0, tend = 0, ttb = 0, te2 = 0, tbtri = -1;
     float tbt = 0.0f, tbu = 0.0f, tbv = 0.0f;
     float4 c0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), c1 = c0;
+    // Single-mesh form: mesh 0's record is read ONCE, here, instead of by dependent scalar loads in every refill (as wf_trav_i)
+    float m0[16]; float4 r0 = c0, r1 = c0; int nb0 = 0, ne0 = 0, tb0 = 0, e20 = 0, obj0 = 0;
+    if (!MULTI) {
+        auto M = &S.meshes[0];
+#pragma unroll
+        for (int k = 0; k < 16; k++) m0[k] = M->inv_transform[k];
+        nb0 = M->node_begin; ne0 = M->node_end; tb0 = M->tri_begin; e20 = M->e2_begin; obj0 = M->object_index;
+        B.node(nb0, r0, r1);
+    }
 #ifdef PT_TRAV_DIAG
     // developer build: where do the lanes go?  (wave-uniform counters, summed into A.diag at exit)
     unsigned long long dg_trips = 0, dg_bsteps = 0, dg_blanes = 0, dg_lsteps = 0, dg_llanes = 0, dg_refills = 0, dg_rlanes = 0, dg_have = 0;
@@ -1831,9 +1840,19 @@ __global__ __launch_bounds__(BS, (BS == 256 ? PT_TRAV_WAVES : 4)) void wf_trav(W
                 // the ray entered SOME mesh's root box in wf_main; find the first one of THIS launch's meshes it enters
                 // (same root tests, same arithmetic; a ray that enters none of them has nothing to do here)
                 tm = 0;
-                if (enter_next_mesh(S, B, tm, o, d, t_min, t_max, too, tod, tinv, ti, tend, ttb, MULTI ? A.trav_mask : 1u) && (MULTI || tm == 0)) {
+                bool in;
+                if (!MULTI) {
+                    too = xform_point(m0, o); tod = xform_vector(m0, d);                         // as enter_next_mesh: geometry.rs:304, :57, :95, :103
+                    rcp3_exact(tod.x, tod.y, tod.z, tinv.x, tinv.y, tinv.z);
+                    const bool leaf_root = __float_as_int(r1.w) >= 0;
+                    in = leaf_root || slab(mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z), too, tinv, t_min, t_max);
+                    ti = leaf_root ? nb0 : nb0 + 1; tend = ne0; ttb = tb0; te2 = e20;
+                } else {
+                    in = enter_next_mesh(S, B, tm, o, d, t_min, t_max, too, tod, tinv, ti, tend, ttb, A.trav_mask);
+                    if (in) te2 = S.meshes[tm].e2_begin;
+                }
+                if (in) {
                     tbt = t_max; tbtri = -1; tbu = tbv = 0.0f;
-                    te2 = S.meshes[tm].e2_begin;
                     B.node(ti, c0, c1);
                     have = true;
                 }
@@ -1904,7 +1923,7 @@ __global__ __launch_bounds__(BS, (BS == 256 ? PT_TRAV_WAVES : 4)) void wf_trav(W
         const bool ended = have && ti >= tend;
         if (MULTI ? (__popcll(__builtin_amdgcn_ballot_w64(ended)) >= PT_TRAV_PEND || __builtin_amdgcn_ballot_w64(have & (ti < tend)) == 0ull) : true) {
             if (ended) {
-                if (tbtri >= 0) consider(best, tbt, S.meshes[tm].object_index, tbtri, tbu, tbv);
+                if (tbtri >= 0) consider(best, tbt, MULTI ? S.meshes[tm].object_index : obj0, tbtri, tbu, tbv);
                 tm++;
                 if (MULTI && enter_next_mesh(S, B, tm, o, d, t_min, t_max, too, tod, tinv, ti, tend, ttb, A.trav_mask)) {
                     tbt = t_max; tbtri = -1; tbu = tbv = 0.0f;
@@ -1975,8 +1994,20 @@ __global__ __launch_bounds__(BS, 8) void wf_trav_i(WfArgs A) {
     float tbt = 0.0f, tbu = 0.0f, tbv = 0.0f;
     float4 c0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), c1 = c0;
 
+    // Single-mesh form: mesh 0's record — inverse transform, root box, first node, object index — is read ONCE, here, instead of by
+    // four dependent scalar loads in every refill (same values, same operations on them afterwards)
+    float m0[16]; float4 r0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), r1 = r0; int root0 = 0, obj0 = 0;
+    if (!MULTI) {
+        auto M = &S.meshes[0];
+#pragma unroll
+        for (int k = 0; k < 16; k++) m0[k] = M->inv_transform[k];
+        B.node(M->node_begin, r0, r1);
+        root0 = M->i_root; obj0 = M->object_index;
+        if (root0 >= 0) root0 = __float_as_int(IN[2 * root0 + 1].w);                 // the node a ray stands on after a passed root test
+    }
     // the ray has passed (or skipped, for a root that is a leaf) mesh tm's root test: stand on the first node to visit
     auto start_mesh = [&]() {
+        if (!MULTI) { id = root0; if (id >= 0) { c0 = IN[2 * id]; c1 = IN[2 * id + 1]; } tbt = t_max; tbtri = -1; tbu = tbv = 0.0f; return; }
         const int root = S.meshes[tm].i_root;
         id = root;
         if (root >= 0) { id = __float_as_int(IN[2 * root + 1].w); }                  // root box passed with bound t_max: its left child
@@ -2007,8 +2038,14 @@ __global__ __launch_bounds__(BS, 8) void wf_trav_i(WfArgs A) {
                 o = mk3(q0.x, q0.y, q0.z); d = mk3(q0.w, q1.x, q1.y);
                 best.t = hr.t; best.obj = hr.obj; best.tri = -1; best.u = 0.0f; best.v = 0.0f;
                 tm = 0;
-                int ti, tend, ttb;
-                if (enter_next_mesh(S, B, tm, o, d, t_min, t_max, too, tod, tinv, ti, tend, ttb, MULTI ? A.trav_mask : 1u) && (MULTI || tm == 0)) { start_mesh(); have = true; }
+                if (!MULTI) {
+                    too = xform_point(m0, o); tod = xform_vector(m0, d);                         // as enter_next_mesh: geometry.rs:304, :57, :95, :103
+                    rcp3_exact(tod.x, tod.y, tod.z, tinv.x, tinv.y, tinv.z);
+                    if (__float_as_int(r1.w) >= 0 || slab(mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z), too, tinv, t_min, t_max)) { start_mesh(); have = true; }
+                } else {
+                    int ti, tend, ttb;
+                    if (enter_next_mesh(S, B, tm, o, d, t_min, t_max, too, tod, tinv, ti, tend, ttb, A.trav_mask)) { start_mesh(); have = true; }
+                }
             }
             wnext += min(avail, n_idle);
             if (wnext < wend) { const uint32_t wb = blocks_a + ((uint32_t)__builtin_amdgcn_readfirstlane((int)wnext) >> 8); while (A.in_blkpfx[wlo + 1] <= wb) wlo++; }
@@ -2053,7 +2090,7 @@ __global__ __launch_bounds__(BS, 8) void wf_trav_i(WfArgs A) {
         const bool ended = have && id == kIdEnd;
         if (MULTI ? (__popcll(__builtin_amdgcn_ballot_w64(ended)) >= PT_TRAV_PEND || __builtin_amdgcn_ballot_w64(have & (id != kIdEnd)) == 0ull) : true) {
             if (ended) {
-                if (tbtri >= 0) consider(best, tbt, S.meshes[tm].object_index, tbtri, tbu, tbv);
+                if (tbtri >= 0) consider(best, tbt, MULTI ? S.meshes[tm].object_index : obj0, tbtri, tbu, tbv);
                 tm++;
                 int ti, tend, ttb;
                 if (MULTI && enter_next_mesh(S, B, tm, o, d, t_min, t_max, too, tod, tinv, ti, tend, ttb, A.trav_mask)) start_mesh();
