@@ -717,11 +717,15 @@ __device__ __forceinline__ void intersect_list(const DScene& S, f3 o, f3 d, floa
         const int end = S.n_list_tri;
         for (; k + 1 < end; k += 2) {
             auto r0 = &L[k]; auto r1 = &L[k + 1];
+            // both records' constants are asked for BEFORE the first test: its reciprocal's range check is a branch, and scalar loads
+            // placed behind it would wait out their latency a second time per trip
+            const f3 a0 = ld3(r0->f), p0 = ld3(r0->f + 3), q0 = ld3(r0->f + 6), a1 = ld3(r1->f), p1 = ld3(r1->f + 3), q1 = ld3(r1->f + 6);
+            const int i0 = r0->index, i1 = r1->index;
             float t0, u0, v0, t1, u1, v1;
-            bool ok0 = tri_t(o, d, ld3(r0->f), ld3(r0->f + 3), ld3(r0->f + 6), t_min, t_max, t0, u0, v0);
-            bool ok1 = tri_t(o, d, ld3(r1->f), ld3(r1->f + 3), ld3(r1->f + 6), t_min, t_max, t1, u1, v1);
-            consider_list(best, have, ok0, t0, r0->index, -1);
-            consider_list(best, have, ok1, t1, r1->index, -1);
+            bool ok0 = tri_t(o, d, a0, p0, q0, t_min, t_max, t0, u0, v0);
+            bool ok1 = tri_t(o, d, a1, p1, q1, t_min, t_max, t1, u1, v1);
+            consider_list(best, have, ok0, t0, i0, -1);
+            consider_list(best, have, ok1, t1, i1, -1);
         }
         for (; k < end; k++) {
             auto r0 = &L[k];
@@ -1721,14 +1725,29 @@ __device__ __forceinline__ uint32_t wf_entry_of(const PT_CONST_AS uint32_t* blkp
     while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (blkpfx[mid] <= block) lo = mid; else hi = mid; }
     return lo;
 }
-// per lane: slot v -> position in st_out; false = empty slot.  `lo0`: a table entry at or before the slot's (the wave's cursor)
-__device__ __forceinline__ bool wf_slot(const WfArgs& A, uint32_t blocks_a, uint32_t v, uint32_t lo0, uint32_t& pos) {
+// The wave's cursor into the table: the entry of the block its chunk STARTS in, with that entry's first block and path count —
+// wave-uniform, fetched by scalar loads once per chunk.  A chunk is at most 256 slots, so nearly every slot a wave hands out lies
+// in that very block and its position is arithmetic on registers; only a chunk that straddles two blocks (an odd chunk length in a
+// short work list) sends lanes through the table.
+struct WfCur { uint32_t lo, block, first, count; };
+__device__ __forceinline__ WfCur wf_cur_at(const WfArgs& A, uint32_t blocks_a, uint32_t slot) {     // slot: wave-uniform
+    WfCur c;
+    c.block = blocks_a + (slot >> 8);
+    c.lo = wf_entry_of(A.in_blkpfx, c.block);
+    c.first = A.in_blkpfx[c.lo]; c.count = A.in_count[c.lo];
+    return c;
+}
+// per lane: slot v -> position in st_out; false = empty slot
+__device__ __forceinline__ bool wf_slot(const WfArgs& A, uint32_t blocks_a, uint32_t v, const WfCur& cur, uint32_t& pos) {
     const uint32_t b = blocks_a + (v >> 8);
-    uint32_t lo = lo0;
-    while (A.in_blkpfx[lo + 1] <= b) lo++;                 // in_blkpfx[2 kWfShards] = all blocks > b
-    const uint32_t local = (b - A.in_blkpfx[lo]) * (uint32_t)kBlock + (v & 255u);
+    uint32_t lo = cur.lo, first = cur.first, count = cur.count;
+    if (b != cur.block) {                                    // rare: the chunk straddles a block boundary
+        while (A.in_blkpfx[lo + 1] <= b) lo++;               // in_blkpfx[2 kWfShards] = all blocks > b
+        first = A.in_blkpfx[lo]; count = A.in_count[lo];
+    }
+    const uint32_t local = (b - first) * (uint32_t)kBlock + (v & 255u);
     pos = (lo - (uint32_t)kWfShards) * A.region + (A.region - 1u - local);      // class B grows from the back of its shard's region
-    return local < A.in_count[lo];
+    return local < count;
 }
 
 // persistent BVH walker with per-lane dynamic refill from the sharded queues
@@ -1792,7 +1811,8 @@ __global__ __launch_bounds__(BS, (BS == 256 ? PT_TRAV_WAVES : 4)) void wf_trav(W
     if (wnext >= n_q) { wnext = wend = 0; drained = true; }
     // shard of the chunk's first entry, kept wave-uniform (SGPRs): a lane then finds its own shard with a step or two
     // instead of an eight-deep chain of dependent vector loads at every refill
-    uint32_t wlo = drained ? (uint32_t)kWfShards : wf_entry_of(A.in_blkpfx, blocks_a + ((uint32_t)__builtin_amdgcn_readfirstlane((int)wnext) >> 8));
+    WfCur wcur = { (uint32_t)kWfShards, 0u, 0u, 0u };
+    if (!drained) wcur = wf_cur_at(A, blocks_a, (uint32_t)__builtin_amdgcn_readfirstlane((int)wnext));
     bool have = false;
     uint32_t pos = 0;
     f3 o = mk3(0.0f, 0.0f, 0.0f), d = o, too = o, tod = o, tinv = o;
@@ -1827,11 +1847,11 @@ __global__ __launch_bounds__(BS, (BS == 256 ? PT_TRAV_WAVES : 4)) void wf_trav(W
                     base = (uint32_t)__shfl((int)base, 0);
                 }
                 if (base >= n_q) drained = true;
-                else { wnext = base; wend = min(base + chunk, n_q); wlo = wf_entry_of(A.in_blkpfx, blocks_a + ((uint32_t)__builtin_amdgcn_readfirstlane((int)base) >> 8)); }
+                else { wnext = base; wend = min(base + chunk, n_q); wcur = wf_cur_at(A, blocks_a, (uint32_t)__builtin_amdgcn_readfirstlane((int)base)); }
             }
             const uint32_t avail = wend - wnext;
             const uint32_t rank = (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
-            const bool take = !have && rank < avail && wf_slot(A, blocks_a, wnext + rank, wlo, pos);
+            const bool take = !have && rank < avail && wf_slot(A, blocks_a, wnext + rank, wcur, pos);
             if (take) {
                 const float4 q0 = A.st_out[st_idx(0, pos, cap)], q1 = A.st_out[st_idx(1, pos, cap)];
                 const Hit2 hr = *st_hit(A.st_out, pos, cap);
@@ -1985,7 +2005,8 @@ __global__ __launch_bounds__(BS, 8) void wf_trav_i(WfArgs A) {
     uint32_t wnext = wave_id * chunk, wend = min(wnext + chunk, n_q);
     bool drained = false;
     if (wnext >= n_q) { wnext = wend = 0; drained = true; }
-    uint32_t wlo = drained ? (uint32_t)kWfShards : wf_entry_of(A.in_blkpfx, blocks_a + ((uint32_t)__builtin_amdgcn_readfirstlane((int)wnext) >> 8));
+    WfCur wcur = { (uint32_t)kWfShards, 0u, 0u, 0u };
+    if (!drained) wcur = wf_cur_at(A, blocks_a, (uint32_t)__builtin_amdgcn_readfirstlane((int)wnext));
     bool have = false;
     uint32_t pos = 0;
     f3 o = mk3(0.0f, 0.0f, 0.0f), d = o, too = o, tod = o, tinv = o;
@@ -2027,11 +2048,11 @@ __global__ __launch_bounds__(BS, 8) void wf_trav_i(WfArgs A) {
                     base = (uint32_t)__shfl((int)base, 0);
                 }
                 if (base >= n_q) drained = true;
-                else { wnext = base; wend = min(base + chunk, n_q); wlo = wf_entry_of(A.in_blkpfx, blocks_a + ((uint32_t)__builtin_amdgcn_readfirstlane((int)base) >> 8)); }
+                else { wnext = base; wend = min(base + chunk, n_q); wcur = wf_cur_at(A, blocks_a, (uint32_t)__builtin_amdgcn_readfirstlane((int)base)); }
             }
             const uint32_t avail = wend - wnext;
             const uint32_t rank = (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
-            const bool take = !have && rank < avail && wf_slot(A, blocks_a, wnext + rank, wlo, pos);
+            const bool take = !have && rank < avail && wf_slot(A, blocks_a, wnext + rank, wcur, pos);
             if (take) {
                 const float4 q0 = A.st_out[st_idx(0, pos, cap)], q1 = A.st_out[st_idx(1, pos, cap)];
                 const Hit2 hr = *st_hit(A.st_out, pos, cap);
@@ -2048,7 +2069,6 @@ __global__ __launch_bounds__(BS, 8) void wf_trav_i(WfArgs A) {
                 }
             }
             wnext += min(avail, n_idle);
-            if (wnext < wend) { const uint32_t wb = blocks_a + ((uint32_t)__builtin_amdgcn_readfirstlane((int)wnext) >> 8); while (A.in_blkpfx[wlo + 1] <= wb) wlo++; }
         }
         if (__builtin_amdgcn_ballot_w64(have) == 0ull) {
             if (drained) break;
