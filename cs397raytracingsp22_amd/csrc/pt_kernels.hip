@@ -75,7 +75,7 @@
 #define PT_TRAVI_LEAF_W 3   // wf_trav_i: a leaf step is taken when n_leaf * W > n_inner
 #endif
 #ifndef PT_TRAVI_LEAF2
-#define PT_TRAVI_LEAF2 16   // wf_trav_i: a leaf step tests a second triangle when at least this many lanes sit on a leaf again
+#define PT_TRAVI_LEAF2 1    // wf_trav_i: a leaf step tests a second triangle when at least this many lanes sit on a leaf again (end of round 3, cfg4 walker: 24 / 16 / 8 / 4 / 1 -> 192.8 / 189.6 / 186.1 / 187.4 / 186.6 ms)
 #endif
 #ifndef PT_MIN_WAVES
 #ifndef PT_TRAV_PEND
