@@ -1312,8 +1312,8 @@ static int render_tiles_wavefront(mi_ctx* c, const K1Args& k, const mi_camera_de
             // persistent walkers; they leave at once when the queue is empty.  Successive launches merge their meshes' hits
             // into the hit record (strictly closer wins, ties go to the lower Scene.objects index: order-independent)
             const bool ref_walk = ref_mask || c->S.n_meshes > 32;      // meshes 32, 33, ... have no mask bit: they always take the reference walk
-            // Meshes of both kinds: wf_trav and wf_trav_f read the same queue and write different things (the hit record / the
-            // candidate lists; each has its own queue cursor), so they go to two streams and wf_replay, which merges into the hit
+            // Meshes of both kinds: wf_trav and wf_trav_f read the same work list and write different things (the hit record / the
+            // candidate lists; each has its own cursor), so they go to two streams and wf_replay, which merges into the hit
             // record, follows both.  With full grids the F-tree walkers move in as the reference walkers run out of queue and leave
             // (HEAD 98.5 -> 96.5 ms).  Sharing every CU from the start — half the wave slots each — gains nothing: 68 ms for the
             // pair, exactly the 43 + 25 ms they take one after the other (VALU issue 0.71 + 0.34: together they saturate it).
@@ -1330,7 +1330,7 @@ static int render_tiles_wavefront(mi_ctx* c, const K1Args& k, const mi_camera_de
             }
             if (ts_mask) {
                 a.trav_mask = ts_mask;
-                // wf_filter_f keeps the queue entries that enter a two-stage mesh's root box; wf_trav_f and wf_replay work on that list
+                // wf_filter_f keeps the class-B paths whose ray enters a two-stage mesh's root box; wf_trav_f and wf_replay work on that list
                 if (side_by_side) {
                     WF_TIMED_ON(3, c->aux2_stream, launch_wf_filter_f(a, 8u, c->aux2_stream));
                     WF_TIMED_ON(3, c->aux2_stream, launch_wf_trav_f(a, (uint32_t)c->n_cus * conc_travf_bpc, c->aux2_stream));

@@ -8,6 +8,19 @@
 //   K3  fb_unpermute    tile-major gathered buffers -> row-major W*H*3 f32
 //   K4  fb_tonemap_u8   tracing.rs:244-256 (saturate toward white, gamma, quantise)
 //
+// The DEFAULT path is the wavefront pipeline K1w: the paths live in HBM (SoA planes, 72 / 76 bytes per
+// path and pass), one kernel per phase over compacted lists, each with its own register budget:
+//   wf_main       camera rays (iteration 0) / shade the pending hit, scatter, object list + mesh root tests for the new ray;
+//                 compile-time forms per scene content (mesh branch, maps, rare kinds, generic volume boundaries); survivors
+//                 appended per shard in two classes (A: plain Triangle / Plane hit, nothing left to walk; B: the rest)
+//   wf_prefix     shard counters -> block tables of the next pass (also the walkers' work list) + the header for the host
+//   wf_trav       persistent walkers over the class-B blocks, the reference's tree in LDS (nodes + leaf triangles), voted steps
+//   wf_trav_i     the same walk for trees of 64 .. 150 KB: interior nodes in LDS, leaves from global memory, 2 x 1024 threads per CU
+//   wf_filter_f / wf_trav_f / wf_replay   exact two-stage traversal of large meshes: root-box filter -> padded SAH tree of
+//                 16-byte quantised nodes + the reference's triangle test -> replay of the reference's walk over the candidates
+//   wf_reduce     per-pixel sums in sample order (tracing.rs:232-241)
+// K1 (below) are the single-launch variants the pipeline grew out of; they remain selectable as structural cross-checks.
+//
 // Execution model of K1 (DESIGN.md "K1"):
 //   * one lane = one pixel; a wave = an 8x8 pixel block; a 256-thread workgroup = a
 //     32x8 strip of one 32x32 image tile.
