@@ -212,8 +212,9 @@ def report(args, sc, flat, world, backend, route, dt, kernel_ms, pipe, counts, e
                      "kernel": "K1w pipeline pass (wf_main + wf_prefix + wf_trav per segment, wf_reduce)" if wavefront else "single-launch kernel",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": frac,
                      "valu_issue_frac": valu_issue, "valu_lane_frac": valu_lane, "valu_kernel": dom,
-                     "binding": "neither HBM nor VALU issue is saturated: latency of the dependent state gathers / LDS node fetches with "
-                                "partly filled waves (DESIGN.md section 5)",
+                     "binding": "the vector-ALU issue port with partly filled waves: the kernels issue at 0.5-0.75 of the VALU rate with 37-52 "
+                                "of 64 lanes live (a third of the walkers' wave time is ready-but-not-issued); HBM carries the path state at "
+                                "about a quarter of its peak and is not the limit (DESIGN.md section 5)",
                      "traffic": traffic, "traffic_source": traffic_source,
                      "traffic_model_bytes": model_bytes, "path_counts": counts,
                      "kernel_ms": kernel_ms,
