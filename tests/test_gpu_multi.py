@@ -33,6 +33,22 @@ def test_multi_one_device_equals_mi_render(gpu_ctx):
     assert st.samples == rst.samples and st.kernel_ms > 0 and st.total_ms >= st.kernel_ms * 0.5
 
 
+def test_multi_one_device_with_meshes_of_both_kinds(gpu_ctx):
+    """The reference's run() scene (drone + cube through the reference walk, the sphere two-stage: wf_filter_f, wf_trav_f on its own
+    stream, wf_replay) through mi_multi_* on its per-device stream: the same image as mi_render."""
+    sc = scenes.head_scene(96, 80, 8, 10)
+    flat = sc.flatten()
+    gpu_ctx.upload(flat)
+    ref32, _, refsig, _ = gpu_ctx.render(sc.camera, seed=8, want_u8=False, want_sig=True)
+    m = MultiContext(1)
+    try:
+        m.upload(flat)
+        f32, _, sig, _ = m.render(sc.camera, seed=8, want_u8=False, want_sig=True)
+    finally:
+        m.close()
+    assert np.array_equal(sig, refsig) and np.array_equal(f32, ref32, equal_nan=True)
+
+
 def test_multi_error_paths():
     from cs397raytracingsp22_amd import abi
     with pytest.raises(abi.MiError) as ei:
