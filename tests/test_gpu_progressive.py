@@ -11,9 +11,10 @@ from cs397raytracingsp22_amd.progressive import ProgressiveRender
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("name", ["config2", "config5"])
+@pytest.mark.parametrize("name", ["config2", "config5", "head"])
 def test_slices_with_checkpoint_equal_one_call(gpu_ctx, tmp_path, name):
-    sc = scenes.config2(160, 96, 16, 10) if name == "config2" else scenes.config5(96, 64, 25, 50)
+    sc = {"config2": lambda: scenes.config2(160, 96, 16, 10), "config5": lambda: scenes.config5(96, 64, 25, 50),
+          "head": lambda: scenes.head_scene(80, 64, 12, 10)}[name]()         # head: meshes of both kinds (reference walk + two-stage)
     flat = sc.flatten()
     gpu_ctx.upload(flat)
     want, _, want_sig, _ = gpu_ctx.render(sc.camera, seed=9, want_u8=False, want_sig=True)
