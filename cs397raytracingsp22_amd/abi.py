@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libmi_rt.so")
 MI_TILE = 32
 
 # status codes (mi_status)
-MI_RT_ABI_VERSION = 4      # include/mi_rt.h
+MI_RT_ABI_VERSION = 5      # include/mi_rt.h
 MI_OK, MI_ERR_INVALID, MI_ERR_UNSUPPORTED, MI_ERR_NO_DEVICE, MI_ERR_HIP, MI_ERR_OOM, MI_ERR_NO_SCENE = 0, -1, -2, -3, -4, -5, -6
 # material kinds
 MI_MAT_LAMBERTIAN, MI_MAT_METAL, MI_MAT_DIELECTRIC, MI_MAT_PARAMETERIZED, MI_MAT_ISOTROPIC = range(5)
@@ -110,7 +110,7 @@ EXPORTS = [
     "mi_ctx_create", "mi_ctx_destroy", "mi_scene_upload", "mi_render", "mi_compact_size",
     "mi_render_tiles_device", "mi_unpermute_device", "mi_tonemap_device", "mi_last_kernel_ms",
     "mi_reserve", "mi_render_samples_device", "mi_last_pipeline_ms", "mi_last_pipeline_counts", "mi_last_diag", "mi_selftest", "mi_last_error", "mi_abi_version",
-    "mi_multi_create", "mi_multi_destroy", "mi_multi_device_count", "mi_multi_context", "mi_multi_scene_upload", "mi_multi_reserve", "mi_multi_render",
+    "mi_multi_create", "mi_multi_create_loopback", "mi_multi_destroy", "mi_multi_device_count", "mi_multi_context", "mi_multi_scene_upload", "mi_multi_reserve", "mi_multi_render",
 ]
 
 _lib = None
@@ -176,6 +176,8 @@ def load() -> C.CDLL:
     lib.mi_selftest.restype = C.c_int
     lib.mi_multi_create.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(vp)]
     lib.mi_multi_create.restype = C.c_int
+    lib.mi_multi_create_loopback.argtypes = [C.c_int, C.c_int, C.POINTER(vp)]
+    lib.mi_multi_create_loopback.restype = C.c_int
     lib.mi_multi_destroy.argtypes = [vp]
     lib.mi_multi_destroy.restype = None
     lib.mi_multi_device_count.argtypes = [vp]

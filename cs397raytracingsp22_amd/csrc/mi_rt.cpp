@@ -849,8 +849,8 @@ static void make_camera(const mi_camera_desc* cam, DCamera* C) {
 // per iteration — the grid of the next wf_main — which arrives on a second stream while wf_trav runs, so
 // the compute stream never waits for the host; the call still returns only when the frame is done.
 //
-// Memory: path state is streamed through HBM — 2 x 96 B (ping/pong) + 4 B queue + 16 B sample
-// slot per path.  The batch is sized to the free HBM (288 GB on MI355X: the whole 1080p/256 spp
+// Memory: path state is streamed through HBM — 2 x 96 B (ping/pong) + 16 B sample slot per path
+// (kWfBytesPerPath; the walkers read the class-B lists, there is no traversal queue).  The batch is sized to the free HBM (288 GB on MI355X: the whole 1080p/256 spp
 // frame, 531 M paths = 112 GB, is ONE batch), halved on allocation failure.
 static const int kHdrRing = 16;        // pinned header slots (wf_prefix -> host), one per pass in flight
 static const int kRunAhead = 3;        // passes the host may launch before it has read the header of an earlier one
@@ -1634,6 +1634,10 @@ struct mi_multi {
     std::vector<void*> d_compact; std::vector<size_t> compact_bytes;
     std::vector<void*> d_sig; std::vector<size_t> sig_bytes;
     void* d_sig_image = nullptr; size_t sig_image_bytes = 0;
+    // test transport (mi_multi_create_loopback): every rank on ONE device, no RCCL; the exchange is a D2D copy per peer on the
+    // peer's stream, ordered into device 0's stream by ev_sent[r]
+    bool loopback = false;
+    std::vector<hipEvent_t> ev_sent;
 };
 
 #define RCCL_TRY(expr)                                                                              \
@@ -1649,6 +1653,7 @@ extern "C" void mi_multi_destroy(mi_multi* m) {
         (void)hipSetDevice(m->devices[r]);
         (void)hipDeviceSynchronize();
         if (r < m->comm.size() && m->comm[r]) (void)g_rccl.CommDestroy(m->comm[r]);
+        if (r < m->ev_sent.size() && m->ev_sent[r]) (void)hipEventDestroy(m->ev_sent[r]);
         if (r < m->d_compact.size() && m->d_compact[r]) (void)hipFree(m->d_compact[r]);
         if (r < m->d_sig.size() && m->d_sig[r]) (void)hipFree(m->d_sig[r]);
         if (r == 0 && m->d_sig_image) (void)hipFree(m->d_sig_image);
@@ -1689,6 +1694,26 @@ extern "C" int mi_multi_create(int n_devices, const int* devices, mi_multi** out
     return MI_OK;
 }
 
+extern "C" int mi_multi_create_loopback(int n_contexts, int device, mi_multi** out) {
+    if (!out) return fail(MI_ERR_INVALID, "mi_multi_create_loopback: out is NULL");
+    *out = nullptr;
+    if (n_contexts < 1 || n_contexts > 64) return fail(MI_ERR_INVALID, "mi_multi_create_loopback: n_contexts %d out of range", n_contexts);
+    mi_multi* m = new mi_multi();
+    m->loopback = true;
+    m->devices.assign((size_t)n_contexts, device);
+    m->ctx.assign((size_t)n_contexts, nullptr); m->ev_sent.assign((size_t)n_contexts, nullptr);
+    m->d_compact.assign((size_t)n_contexts, nullptr); m->compact_bytes.assign((size_t)n_contexts, 0);
+    m->d_sig.assign((size_t)n_contexts, nullptr); m->sig_bytes.assign((size_t)n_contexts, 0);
+    for (int r = 0; r < n_contexts; r++) {
+        int rc = mi_ctx_create(device, &m->ctx[(size_t)r]);
+        if (rc == MI_OK && hipEventCreateWithFlags(&m->ev_sent[(size_t)r], hipEventDisableTiming) != hipSuccess)
+            rc = fail(MI_ERR_HIP, "hipEventCreateWithFlags failed");
+        if (rc != MI_OK) { const std::string msg = g_err; mi_multi_destroy(m); g_err = msg; return rc; }
+    }
+    *out = m;
+    return MI_OK;
+}
+
 extern "C" int mi_multi_device_count(const mi_multi* m) { return m ? (int)m->ctx.size() : 0; }
 extern "C" mi_ctx* mi_multi_context(const mi_multi* m, int rank) {
     if (!m || rank < 0 || (size_t)rank >= m->ctx.size()) { (void)fail(MI_ERR_INVALID, "mi_multi_context: rank %d out of range", rank); return nullptr; }
@@ -1708,6 +1733,17 @@ template <class F> static int on_every_device(mi_multi* m, F fn) {
     return MI_OK;
 }
 
+// Loopback ranks share one card: "60 % of the free HBM" per rank would be claimed `world` times over by threads that all look at
+// the same free figure.  With no budget given each rank gets an even share of that default (what the ranks already hold counts as
+// free).  ~0 = failure (message recorded).  The RCCL route (one rank per device) passes the caller's value through.
+static uint64_t loopback_budget(const mi_multi* m, uint64_t max_state_bytes) {
+    if (!m->loopback || max_state_bytes != 0 || m->ctx.size() < 2) return max_state_bytes;
+    size_t free_b = 0, total_b = 0;
+    if (hipSetDevice(m->devices[0]) != hipSuccess || hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)fail(MI_ERR_HIP, "hipMemGetInfo failed"); return ~0ull; }
+    for (const mi_ctx* c : m->ctx) free_b += c->wf_a_bytes + c->wf_b_bytes + c->wf_samp_bytes + c->cand_bytes + c->cand_hdr_bytes;
+    return (uint64_t)((double)free_b * 0.6 / (double)m->ctx.size());
+}
+
 extern "C" int mi_multi_scene_upload(mi_multi* m, const mi_scene_desc* scene) {
     if (!m || !scene) return fail(MI_ERR_INVALID, "mi_multi_scene_upload: NULL argument");
     // the scene is small (KBs .. a few hundred MB of textures) and 288 GB per GPU make replication free
@@ -1717,6 +1753,7 @@ extern "C" int mi_multi_scene_upload(mi_multi* m, const mi_scene_desc* scene) {
 extern "C" int mi_multi_reserve(mi_multi* m, const mi_camera_desc* cam, uint64_t max_state_bytes) {
     if (!m) return fail(MI_ERR_INVALID, "mi_multi_reserve: NULL argument");
     const int world = (int)m->ctx.size();
+    if ((max_state_bytes = loopback_budget(m, max_state_bytes)) == ~0ull) return MI_ERR_HIP;
     return on_every_device(m, [&](int r) { return mi_reserve(m->ctx[(size_t)r], cam, world, max_state_bytes); });
 }
 
@@ -1747,10 +1784,13 @@ extern "C" int mi_multi_render(mi_multi* m, const mi_camera_desc* cam, const mi_
 
     // ---- every device renders its tiles (one host thread each; the wavefront pipeline drives its passes from the host) ----
     std::vector<mi_stats> st((size_t)world);
+    const uint64_t budget = loopback_budget(m, opts->max_state_bytes);
+    if (budget == ~0ull) return MI_ERR_HIP;
     rc = on_every_device(m, [&](int r) {
         mi_ctx* c = m->ctx[(size_t)r];
         if (hipSetDevice(c->device) != hipSuccess) return fail(MI_ERR_HIP, "hipSetDevice failed");
         mi_render_opts o = *opts;
+        o.max_state_bytes = budget;
         o.rank = r; o.world = world; o.want_signature = want_sig ? 1 : 0;
         const int rr = render_tiles(c, cam, &o, (float*)m->d_compact[(size_t)r], want_sig ? (uint32_t*)m->d_sig[(size_t)r] : nullptr, c->stream, &st[(size_t)r]);
         if (rr != MI_OK) return rr;
@@ -1764,7 +1804,18 @@ extern "C" int mi_multi_render(mi_multi* m, const mi_camera_desc* cam, const mi_
     // ---- the frame's single exchange: fan-in of the compact buffers to device 0 (one group, issued from this thread) ----
     // A failure between GroupStart and GroupEnd must not leave the group open (every later RCCL call of this thread would
     // silently join it): the first error is kept, the remaining calls of the group are skipped, GroupEnd always runs.
-    if (world > 1) {
+    if (world > 1 && m->loopback) {
+        // test transport: the same slices to the same offsets, each Send / Recv pair replaced by one copy on the SENDER's stream
+        // (behind its render) that device 0's stream waits for — the ordering the RCCL pair gives
+        for (int r = 1; r < world; r++) {
+            hipStream_t sr = m->ctx[(size_t)r]->stream;
+            HIP_TRY(hipMemcpyAsync((float*)m->d_compact[0] + (size_t)r * slice_f, m->d_compact[(size_t)r], slice_f * sizeof(float), hipMemcpyDeviceToDevice, sr));
+            if (want_sig)
+                HIP_TRY(hipMemcpyAsync((uint32_t*)m->d_sig[0] + (size_t)r * slice_s, m->d_sig[(size_t)r], slice_s * 4, hipMemcpyDeviceToDevice, sr));
+            HIP_TRY(hipEventRecord(m->ev_sent[(size_t)r], sr));
+            HIP_TRY(hipStreamWaitEvent(c0->stream, m->ev_sent[(size_t)r], 0));
+        }
+    } else if (world > 1) {
         ncclResult_t first = ncclSuccess; const char* what = "";
         auto step = [&](ncclResult_t r, const char* name) { if (first == ncclSuccess && r != ncclSuccess) { first = r; what = name; } return first == ncclSuccess; };
         RCCL_TRY(g_rccl.GroupStart());

@@ -90,10 +90,10 @@
 #ifndef PT_TRAVI_LEAF2
 #define PT_TRAVI_LEAF2 1    // wf_trav_i: a leaf step tests a second triangle when at least this many lanes sit on a leaf again (end of round 3, cfg4 walker: 24 / 16 / 8 / 4 / 1 -> 192.8 / 189.6 / 186.1 / 187.4 / 186.6 ms)
 #endif
-#ifndef PT_MIN_WAVES
 #ifndef PT_TRAV_PEND
 #define PT_TRAV_PEND 16    // walkers over several meshes: lanes that have finished one mesh wait until this many can take the next root tests together (HEAD walker: 4 / 8 / 16 / 24 -> 40.9 / 38.1 / 36.3 / 37.0 ms; on the spot: 43.4)
 #endif
+#ifndef PT_MIN_WAVES
 #define PT_MIN_WAVES 4      // waves per SIMD the register allocator must leave room for (<= 128 VGPRs)
 #endif
 
@@ -2283,7 +2283,9 @@ __global__ __launch_bounds__(256) void wf_filter_f(WfArgs A) {
         base = (uint32_t)__shfl((int)base, 0);
         if (keep) buf[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = pos;
         __syncthreads();
-        if (n_buf >= 1024u) flush();
+        const uint32_t n_now = n_buf;       // read between two barriers: no wave may add to n_buf (next trip) before every wave has
+        __syncthreads();                    // read it, or the waves could disagree about entering flush() and its barriers
+        if (n_now >= 1024u) flush();
     }
     flush();
 }

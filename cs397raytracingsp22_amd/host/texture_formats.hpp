@@ -250,6 +250,7 @@ inline bool decode_tiff(const std::vector<uint8_t>& d, int& W, int& H, std::vect
     const uint32_t comp = scalar(259, 1), photo = scalar(262, 0xffff), spp = scalar(277, 1), planar = scalar(284, 1), pred = scalar(317, 1);
     if (find(322).ok || find(324).ok) return false;         // tiles
     if (planar != 1 || spp < 1 || spp > 8 || (pred != 1 && pred != 2)) return false;
+    if (w * h * spp > kMaxPixels * 4) return false;         // decoded samples, before the conversion to RGB8
     { const Field b = find(258); if (!b.ok) return false; for (uint32_t k = 0; k < b.count && k < spp; k++) if (val(b, k) != 8) return false; }      // absent = 1 bit per sample
     if (!((photo <= 1 && spp >= 1) || (photo == 2 && spp >= 3) || (photo == 3 && spp >= 1))) return false;
     if (comp != 1 && comp != 5 && comp != 8 && comp != 32946 && comp != 32773) return false;
@@ -271,7 +272,6 @@ inline bool decode_tiff(const std::vector<uint8_t>& d, int& W, int& H, std::vect
     std::vector<uint8_t> pix;
     std::vector<uint8_t> strip;
     size_t out_rows = 0;
-    std::vector<uint8_t> img;                               // decoded samples, row_bytes per row
     for (size_t s = 0; s < so.count; s++) {
         const size_t off = val(so, s), cnt = val(sc, s);
         if (!v.has(off, cnt)) return false;
@@ -300,18 +300,19 @@ inline bool decode_tiff(const std::vector<uint8_t>& d, int& W, int& H, std::vect
             if ((rc != Z_OK && rc != Z_BUF_ERROR) || got != want) return false;
         }
         if (pred == 2) for (size_t r = 0; r < rows; r++) { uint8_t* p = &strip[r * row_bytes]; for (size_t k = spp; k < row_bytes; k++) p[k] = (uint8_t)(p[k] + p[k - spp]); }
-        img.insert(img.end(), strip.begin(), strip.end());
+        // straight into the RGB8 output, strip by strip: the output only ever grows by what a strip really decoded to
+        const size_t k0 = rgb.size() / 3, nk = rows * w;
+        rgb.resize((k0 + nk) * 3);
+        for (size_t k = 0; k < nk; k++) {
+            const uint8_t* p = &strip[k * spp];
+            uint8_t* o = &rgb[3 * (k0 + k)];
+            if (photo == 2) { o[0] = p[0]; o[1] = p[1]; o[2] = p[2]; }
+            else if (photo == 3) { o[0] = pal[p[0]][0]; o[1] = pal[p[0]][1]; o[2] = pal[p[0]][2]; }
+            else { const uint8_t g = photo == 0 ? (uint8_t)(255 - p[0]) : p[0]; o[0] = o[1] = o[2] = g; }
+        }
         out_rows += rows;
     }
-    if (out_rows != h) return false;
-    rgb.resize(w * h * 3);
-    for (size_t k = 0; k < w * h; k++) {
-        const uint8_t* p = &img[k * spp];
-        uint8_t* o = &rgb[3 * k];
-        if (photo == 2) { o[0] = p[0]; o[1] = p[1]; o[2] = p[2]; }
-        else if (photo == 3) { o[0] = pal[p[0]][0]; o[1] = pal[p[0]][1]; o[2] = pal[p[0]][2]; }
-        else { const uint8_t g = photo == 0 ? (uint8_t)(255 - p[0]) : p[0]; o[0] = o[1] = o[2] = g; }
-    }
+    if (out_rows != h || rgb.size() != w * h * 3) return false;
     W = (int)w; H = (int)h;
     return true;
 }

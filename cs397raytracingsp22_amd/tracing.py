@@ -183,12 +183,21 @@ class MultiContext:
     """mi_multi: N GPUs of one node behind ONE handle (one context, stream and host thread per device inside the
     library; tiles t % N; a single RCCL send/recv fan-in per frame; un-permute and tone-map on device 0)."""
 
-    def __init__(self, n_devices: int, devices=None):
+    def __init__(self, n_devices: int, devices=None, _loopback_device=None):
         self._lib = abi.load()
         self._h = C.c_void_p()
-        arr = (C.c_int * n_devices)(*devices) if devices is not None else None
-        abi.check(self._lib.mi_multi_create(n_devices, arr, C.byref(self._h)))
+        if _loopback_device is not None:
+            abi.check(self._lib.mi_multi_create_loopback(n_devices, _loopback_device, C.byref(self._h)))
+        else:
+            arr = (C.c_int * n_devices)(*devices) if devices is not None else None
+            abi.check(self._lib.mi_multi_create(n_devices, arr, C.byref(self._h)))
         self.n_devices = n_devices
+
+    @classmethod
+    def loopback(cls, n_contexts: int, device: int = 0) -> "MultiContext":
+        """mi_multi_create_loopback: the TEST transport — `n_contexts` ranks on one device, the RCCL fan-in replaced by
+        event-ordered device-to-device copies; everything else is mi_multi_render's N >= 2 code."""
+        return cls(n_contexts, _loopback_device=device)
 
     def close(self):
         if self._h:

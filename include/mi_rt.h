@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define MI_RT_ABI_VERSION 4
+#define MI_RT_ABI_VERSION 5
 
 /* ---- status codes (reference: panics via assert!/expect/unwrap, geometry.rs:149-151) ---- */
 typedef enum mi_status {
@@ -324,6 +324,14 @@ int  mi_selftest(mi_ctx* ctx, uint64_t* out4);
  * stats->kernel_ms is the slowest device's pipeline pass, stats->total_ms the wall time of the call. */
 typedef struct mi_multi mi_multi;
 int  mi_multi_create(int n_devices, const int* devices, mi_multi** out);
+/* TEST TRANSPORT, not for production use: `n_contexts` ranks that all live on the ONE device `device`, so that everything
+ * mi_multi_render does for N >= 2 — one host thread per rank, every rank's pipeline on its own streams, the r * slice receive
+ * offsets, the un-permute and tone-map with world > 1, the max-over-ranks statistics — runs on a one-GPU machine.  The only
+ * difference from mi_multi_create is the exchange: RCCL is not loaded, and each ncclSend / ncclRecv pair becomes one
+ * device-to-device hipMemcpyAsync on the sender's stream that device 0's stream waits for through an event (the ordering
+ * the RCCL pair gives).  The ranks share the card, so the call is no faster than mi_render; the image is bit-identical to it.
+ * With opts->max_state_bytes == 0 the ranks split the default budget (60 % of the free HBM) evenly. */
+int  mi_multi_create_loopback(int n_contexts, int device, mi_multi** out);
 void mi_multi_destroy(mi_multi* m);
 int  mi_multi_device_count(const mi_multi* m);
 /* The context of device number `rank` (0 .. N-1), owned by `m` and valid until mi_multi_destroy: for the per-device queries

@@ -367,7 +367,7 @@ int orc_scene_create(const mi_scene_desc* d, orc_scene** out) {
         if (v->boundary_kind == MI_OBJ_SPHERE) continue;                /* the inline sphere */
         if (v->boundary_kind == MI_OBJ_SCENE) {
             first = v->boundary_index; count = v->boundary_count; entries = s->boundary_objects;
-            if (first < 0 || count < 0 || first + count > s->n_boundary_objects) { orc_scene_destroy(s); return MI_ERR_INVALID; }
+            if (first < 0 || count < 0 || (int64_t)first + (int64_t)count > (int64_t)s->n_boundary_objects) { orc_scene_destroy(s); return MI_ERR_INVALID; }
         } else { one.kind = v->boundary_kind; one.index = v->boundary_index; entries = &one; }
         for (int k = 0; k < count; k++) {
             const mi_object* e = &entries[first + k]; int n = -1;

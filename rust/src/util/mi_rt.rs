@@ -1,8 +1,11 @@
-//! Source-only Rust binding of include/mi_rt.h for mbk6/CS397RayTracingSP22.
-//! UNVERIFIED IN THIS CONTAINER: there is no cargo/rustc here, so this file has never been
-//! compiled.  It is what a maintainer of the reference would add as `src/util/mi_rt.rs`
-//! (plus `mod mi_rt;` in src/util.rs and `println!("cargo:rustc-link-lib=mi_rt")` in build.rs).
+//! Rust binding of include/mi_rt.h for mbk6/CS397RayTracingSP22: what a maintainer of the reference adds as
+//! `src/util/mi_rt.rs` (rust/README.md lists the other files of the patch set and the five lines of the reference they touch).
+//! UNVERIFIED BY A COMPILER IN THIS CONTAINER: there is no cargo / rustc here.  What IS checked mechanically
+//! (tests/test_abi.py): every `#[repr(C)]` struct below against the C header field by field (order, type, count), every
+//! `extern "C"` function against the header's prototypes (name, argument count and types), the numeric constants, and the
+//! bracket structure of every file of the patch set.
 #![allow(non_camel_case_types, dead_code)]
+use std::collections::HashMap;
 use std::os::raw::{c_char, c_int, c_void};
 
 #[repr(C)] #[derive(Clone, Copy)] pub struct mi_material { pub kind: i32, pub albedo: [f32; 3], pub emission: [f32; 3], pub roughness: f32, pub metallic: f32, pub idx_of_refraction: f32 }
@@ -36,10 +39,18 @@ use std::os::raw::{c_char, c_int, c_void};
 pub enum mi_ctx {}
 pub enum mi_multi {}
 pub const MI_OPT_NO_TILE_MASKS: u32 = 1; pub const MI_OPT_REFERENCE_WALK: u32 = 2; pub const MI_OPT_TWO_STAGE: u32 = 4;
+pub const MI_RT_ABI_VERSION: c_int = 5;
+// mi_material_kind / mi_object_kind / projection and shading modes (include/mi_rt.h)
+pub const MI_MAT_LAMBERTIAN: i32 = 0; pub const MI_MAT_METAL: i32 = 1; pub const MI_MAT_DIELECTRIC: i32 = 2;
+pub const MI_MAT_PARAMETERIZED: i32 = 3; pub const MI_MAT_ISOTROPIC: i32 = 4;
+pub const MI_OBJ_SPHERE: i32 = 0; pub const MI_OBJ_TRIANGLE: i32 = 1; pub const MI_OBJ_PLANE: i32 = 2;
+pub const MI_OBJ_VOLUME: i32 = 3; pub const MI_OBJ_MESH: i32 = 4; pub const MI_OBJ_SCENE: i32 = 5;
+pub const MI_PROJ_ORTHOGRAPHIC: i32 = 0; pub const MI_PROJ_PERSPECTIVE: i32 = 1;
+pub const MI_SHADE_PHONG: i32 = 0; pub const MI_SHADE_PATHTRACE: i32 = 1;
 
 #[link(name = "mi_rt")]
 extern "C" {
-    // every entry point of include/mi_rt.h (ABI 4), in header order
+    // every entry point of include/mi_rt.h (ABI 5), in header order
     pub fn mi_ctx_create(device: c_int, out: *mut *mut mi_ctx) -> c_int;
     pub fn mi_ctx_destroy(ctx: *mut mi_ctx);
     pub fn mi_scene_upload(ctx: *mut mi_ctx, scene: *const mi_scene_desc) -> c_int;
@@ -63,6 +74,7 @@ extern "C" {
     pub fn mi_selftest(ctx: *mut mi_ctx, out4: *mut u64) -> c_int;
     // N GPUs of one node behind one blocking call (RCCL fan-in inside the library)
     pub fn mi_multi_create(n_devices: c_int, devices: *const c_int, out: *mut *mut mi_multi) -> c_int;
+    pub fn mi_multi_create_loopback(n_contexts: c_int, device: c_int, out: *mut *mut mi_multi) -> c_int;   // test transport: N ranks on one device
     pub fn mi_multi_destroy(m: *mut mi_multi);
     pub fn mi_multi_device_count(m: *const mi_multi) -> c_int;
     pub fn mi_multi_context(m: *const mi_multi, rank: c_int) -> *mut mi_ctx;
@@ -71,19 +83,71 @@ extern "C" {
     pub fn mi_multi_render(m: *mut mi_multi, cam: *const mi_camera_desc, opts: *const mi_render_opts,
                            out_rgb_f32: *mut f32, out_rgb_u8: *mut u8, out_sig: *mut u32, stats: *mut mi_stats) -> c_int;
     pub fn mi_last_error() -> *const c_char;
-    pub fn mi_abi_version() -> c_int;           // 4: assert at start-up that header and library agree
+    pub fn mi_abi_version() -> c_int;           // 5: assert at start-up that header and library agree
 }
 
-/// Collected in `Scene.objects` order by the additive trait method
-/// `fn flatten(&self, out: &mut SceneBuilder)` on `Intersectable` (tracing.rs:42-47) and
-/// `fn flatten(&self) -> mi_material` on `Material` (materials.rs:12-15).
+
+/// The additive half of `trait Intersectable` (tracing.rs:42-47): `pub trait Intersectable: mi_rt::FlattenObject`.
+/// A supertrait rather than a new method, so that the implementations live in their own `impl` blocks (the
+/// `*_flatten.rs` fragments) and no existing `impl Intersectable for ..` block of the reference is edited.
+/// The default body is what the helper types get that never appear in `Scene.objects` (AABB, BVHNode, IndexedTriangle).
+pub trait FlattenObject {
+    fn flatten(&self, out: &mut SceneBuilder) { out.unsupported(std::any::type_name::<Self>()); }
+}
+/// The additive half of `trait Material` (materials.rs:12-15): `pub trait Material: mi_rt::FlattenMaterial`.
+pub trait FlattenMaterial {
+    fn flatten(&self) -> mi_material;
+}
+
+/// Collects the PODs of a scene in `Scene.objects` order (that order decides ties, tracing.rs:335, and the order of the
+/// RNG draws of ConvexVolume::intersect_ray, geometry.rs:517).  Owns what the PODs point into where the reference does not:
+/// the RGB8 bytes of the textures.  Mesh arrays are borrowed from the `Arc<Mesh>` of the StaticMesh, which outlives the call.
 #[derive(Default)]
 pub struct SceneBuilder {
     pub objects: Vec<mi_object>, pub spheres: Vec<mi_sphere>, pub triangles: Vec<mi_triangle>, pub planes: Vec<mi_plane>,
     pub volumes: Vec<mi_volume>, pub meshes: Vec<mi_mesh>, pub materials: Vec<mi_material>, pub textures: Vec<mi_texture>,
     pub boundary_objects: Vec<mi_object>,
+    /// first reason why this scene cannot run on the GPU path (None = it can)
+    pub unsupported: Option<String>,
+    tex_bytes: Vec<Vec<u8>>,                   // backing store of `textures[i].rgb` (a Vec's heap block does not move when the outer Vec grows)
+    material_ids: HashMap<usize, i32>,         // Arc<dyn Material> data pointer -> index: a shared Arc is one mi_material
+    mesh_ids: HashMap<usize, i32>,             // &StaticMesh address -> index: the same Arc<StaticMesh> listed twice is ONE mi_mesh
+    detached: Vec<Vec<mi_object>>,             // open ConvexVolume boundaries: entries pushed meanwhile are NOT Scene.objects entries
 }
 impl SceneBuilder {
+    pub fn unsupported(&mut self, what: &str) {
+        if self.unsupported.is_none() { self.unsupported = Some(what.to_string()); }
+    }
+    /// One entry of Scene.objects — or, inside a ConvexVolume boundary, one entry of that boundary.
+    pub fn push_object(&mut self, kind: i32, index: i32) {
+        let o = mi_object { kind: kind, index: index };
+        match self.detached.last_mut() { Some(list) => list.push(o), None => self.objects.push(o) }
+    }
+    pub fn in_boundary(&self) -> bool { !self.detached.is_empty() }
+    pub fn begin_boundary(&mut self) { self.detached.push(Vec::new()); }
+    pub fn end_boundary(&mut self) -> Vec<mi_object> { self.detached.pop().unwrap_or_default() }
+    /// Index of `m` in `materials`; an Arc seen before (same data pointer) is not pushed again.
+    pub fn material(&mut self, m: &std::sync::Arc<dyn super::materials::Material + Send + Sync>) -> i32 {
+        let key = std::sync::Arc::as_ptr(m) as *const () as usize;
+        if let Some(&i) = self.material_ids.get(&key) { return i; }
+        let i = self.materials.len() as i32;
+        self.materials.push(m.flatten());
+        self.material_ids.insert(key, i);
+        i
+    }
+    /// Index of a texture given as tightly packed RGB8 rows, top row first (texture.rs:30 `get_pixel(x, y).to_rgb()`).
+    pub fn texture_rgb8(&mut self, width: u32, height: u32, rgb: Vec<u8>) -> i32 {
+        assert_eq!(rgb.len(), width as usize * height as usize * 3);
+        let i = self.textures.len() as i32;
+        self.tex_bytes.push(rgb);
+        let p = self.tex_bytes.last().unwrap().as_ptr();
+        self.textures.push(mi_texture { width: width as i32, height: height as i32, rgb: p });
+        i
+    }
+    pub fn mesh_index(&self, key: usize) -> Option<i32> { self.mesh_ids.get(&key).copied() }
+    pub fn remember_mesh(&mut self, key: usize, index: i32) { self.mesh_ids.insert(key, index); }
+
+    /// The POD view; valid while `self` (and the scene it was flattened from) is alive and unchanged.
     pub fn desc(&self) -> mi_scene_desc {
         mi_scene_desc {
             objects: self.objects.as_ptr(), n_objects: self.objects.len() as i32,
@@ -95,8 +159,15 @@ impl SceneBuilder {
             materials: self.materials.as_ptr(), n_materials: self.materials.len() as i32,
             textures: self.textures.as_ptr(), n_textures: self.textures.len() as i32,
             boundary_objects: self.boundary_objects.as_ptr(), n_boundary_objects: self.boundary_objects.len() as i32,
-            point_light_pos: [0.0, 1.0, 5.0], ambient: [0.1, 0.1, 0.1],   // caller overwrites from Scene
+            point_light_pos: [0.0, 1.0, 5.0], ambient: [0.1, 0.1, 0.1],   // the caller overwrites both from Scene (tracing.rs:216-217)
         }
     }
 }
-pub fn _unused(_: *mut c_void) {}
+
+/// `mi_last_error()` of this thread as a String.
+pub fn last_error() -> String {
+    unsafe {
+        let p = mi_last_error();
+        if p.is_null() { String::new() } else { std::ffi::CStr::from_ptr(p).to_string_lossy().into_owned() }
+    }
+}

@@ -42,6 +42,26 @@ def test_virtual_ranks_assemble_bit_identical_image(gpu_ctx):
         assert np.array_equal(gathered.reshape(world, -1, 3)[r_of, idx], ref32)
 
 
+@pytest.mark.parametrize("width", [192, 250, 224])
+def test_virtual_ranks_where_the_tile_columns_share_a_factor_with_the_world(gpu_ctx, width):
+    """The coprime row length of the tile numbering (mi_rt.cpp tile_counts) changes the partition whenever the image's tile
+    columns share a factor with the rank count: 192 px = 6 columns (7 for 2 / 3 / 4 / 8 ranks), 250 px = 8 columns with a
+    partial last one (9 for 2 / 4 / 8 ranks, 8 for 3), 224 px = 7 columns (already coprime with all four).  The surplus
+    columns hold no pixel; the assembled image is mi_render's bit for bit and dist.compact_index is K3's mapping."""
+    sc = scenes.config2(width, 70, 4, 10)
+    gpu_ctx.upload(sc.flatten())
+    ref32, ref8, _, _ = gpu_ctx.render(sc.camera, seed=6)
+    for world in (2, 3, 4, 8):
+        img, u8, gathered = assemble(gpu_ctx, sc.camera, world, seed=6)
+        assert np.array_equal(img, ref32) and np.array_equal(u8, ref8), (width, world)
+        r_of, idx = pdist.compact_index(width, 70, world)
+        assert np.array_equal(gathered.reshape(world, -1, 3)[r_of, idx], ref32), (width, world)
+        # everything outside the image — the surplus columns, the padding slots, the ragged edges — is zero
+        used = np.zeros(gathered.reshape(world, -1, 3).shape[:2], bool)
+        used[r_of, idx] = True
+        assert not gathered.reshape(world, -1, 3)[~used].any(), (width, world)
+
+
 def test_compact_size_matches_host_arithmetic(gpu_ctx):
     from cs397raytracingsp22_amd import compact_size
     sc = scenes.config2(1920, 1080, 4)
@@ -136,7 +156,7 @@ def test_wavefront_batching_is_exact(gpu_ctx):
     gpu_ctx.upload(flat)
     ref32, ref8, refsig, _ = gpu_ctx.render(sc.camera, seed=11, want_sig=True)
     npix = pdist.tiles_padded(160, 96, 1) * pdist.TILE_PIXELS
-    bytes_per_path = 2 * 6 * 16 + 2 * 4 + 16       # mi_rt.cpp kWfBytesPerPath: ping + pong state, two queue words, sample slot
+    bytes_per_path = 2 * 6 * 16 + 16       # mi_rt.cpp kWfBytesPerPath: ping + pong state (6 float4 planes each), sample slot; no queue
     small = Context(0)
     try:
         small.upload(flat)

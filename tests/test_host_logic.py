@@ -101,6 +101,23 @@ def test_tile_partition_arithmetic():
         assert np.unique(key).size == W * H
 
 
+def test_library_partition_equals_the_python_mirror_without_a_gpu():
+    """mi_compact_size (mi_rt.cpp tile_counts, what mi_multi_render and the RCCL slice sizes use) against dist.tile_grid for
+    widths whose tile-column count is / is not coprime with the world and whose last column is / is not partial.  No GPU."""
+    from cs397raytracingsp22_amd import Camera, compact_size
+    for W in (32, 75, 192, 203, 224, 250, 256, 1920, 3840):
+        for H in (41, 64, 1080):
+            cam = Camera(screen_width=W, screen_height=H, aa_sample_count=4)
+            for world in (1, 2, 3, 4, 5, 6, 7, 8):
+                total, padded = compact_size(cam, world)
+                tx, ty, t2 = dist.tile_grid(W, H, world)
+                assert total == t2 == tx * ty and padded == dist.tiles_padded(W, H, world), (W, H, world)
+                assert np.gcd(tx, world) == 1 and tx >= (W + 31) // 32
+                # every rank owns `padded` or `padded - 1` tiles, and never none when there are at least `world` tiles
+                counts = [len(dist.tiles_of_rank(W, H, r, world)) for r in range(world)]
+                assert max(counts) == padded and min(counts) >= padded - 1
+
+
 GLOO_WORKER = """
 import os, sys
 sys.path.insert(0, {root!r})
