@@ -165,11 +165,23 @@ def report(args, sc, flat, world, backend, route, dt, kernel_ms, pipe, counts, e
     samples_per_frame = cam.screen_width * cam.screen_height * cam.aa_sample_count
     ms_per_step = dt / args.steps * 1e3
     value = samples_per_frame * args.steps / dt / 1e6
-    b_sample, segs = algorithmic_bytes_per_sample(args.config, cam.aa_sample_count)
+    b_sample, segs_oracle = algorithmic_bytes_per_sample(args.config, cam.aa_sample_count)
     wavefront = args.variant in (0, 7)
+    # What the headline counts.  `value` divides ALL W*H*spp samples by the time, as the metric is defined; the samples of dead
+    # tiles (32x32 tiles from which no camera ray can reach anything: black by tracing.rs:306, no ray is generated) cost nothing,
+    # so the rate over the pixels that see something is printed beside it, and the segment rate comes from the device's own count of
+    # Scene::intersect_ray evaluations of the timed steps — not from the oracle's per-sample mean, which counts one segment for
+    # every void sample.  `counts` are device 0's: with N > 1 ranks the segment figures are left out.
+    dead_frac = live_rate = segs = mseg = None
+    if counts and wavefront and world == 1:
+        dead_frac = counts["dead_tile_samples"] / float(samples_per_frame)
+        live_rate = (samples_per_frame - counts["dead_tile_samples"]) * args.steps / dt / 1e6
+        if counts.get("segments"):
+            segs = counts["segments"] / float(samples_per_frame)
+            mseg = counts["segments"] * args.steps / dt / 1e6
     per_step = {k: (v / args.steps) for k, v in pipe.items()}
     # ---- HBM roofline of the dominant kernel group (the pipeline pass of ONE device) ----
-    pmc, why_not = (committed_pmc(args.config) if world == 1 and not args.spp and wavefront and not args.flags
+    pmc, why_not = (committed_pmc(args.config) if world == 1 and not args.spp and wavefront and not args.flags and not args.max_state_gb
                     else (None, "not the profiled configuration"))
     model_bytes = traffic_model(counts, flat.desc.n_meshes) if (wavefront and counts and counts["passes"]) else None
     if pmc is not None and pmc.get("hbm_bytes_per_launch"):
@@ -181,6 +193,11 @@ def report(args, sc, flat, world, backend, route, dt, kernel_ms, pipe, counts, e
         traffic, traffic_source = None, why_not
     achieved = traffic / (kernel_ms * 1e-3) / 1e9 if (traffic and kernel_ms) else None
     frac = achieved / HBM_PEAK_GBS if achieved is not None else None
+    # The guide's x2 on FETCH_SIZE is calibrated on wide coalesced reads; the walkers' per-ray gathers are not that, so the
+    # corrected figure is an upper bound and the raw counters a lower one: the fraction is a range.
+    frac_raw = None
+    if pmc is not None and pmc.get("hbm_bytes_raw_per_launch") and kernel_ms:
+        frac_raw = float(pmc["hbm_bytes_raw_per_launch"]) / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
     if frac is not None:
         assert frac <= 1.0, f"HBM roofline fraction {frac} > 1: traffic accounting is wrong"
     valu = dom = None
@@ -201,8 +218,11 @@ def report(args, sc, flat, world, backend, route, dt, kernel_ms, pipe, counts, e
         "config": {"workload": f"{args.config}: {CONFIGS[args.config]}",
                    "width": cam.screen_width, "height": cam.screen_height, "spp": cam.aa_sample_count,
                    "path_depth": cam.path_depth, "parallelism": f"tiles32x32_mod{world}",
+                   "max_state_gb": (args.max_state_gb or "library default"),
                    "caller": "python ctypes over the C ABI (include/mi_rt.h)", "route": route,
-                   "segments_per_sample": segs, "msegments_per_s": (value * segs if segs else None),
+                   "dead_tile_frac": dead_frac, "live_pixel_msamples_per_s": live_rate,
+                   "segments_per_sample": segs, "msegments_per_s": mseg, "segments_source": "device counter (wf_main), last timed step",
+                   "segments_per_sample_oracle": segs_oracle,
                    "multi_gpu_note": "N>1 numbers exist only where this script ran on a multi-GPU node; "
                                      "the builder's own N>1 figures are single-GPU rehearsals (DESIGN.md section 6)"},
         # Two resources bound this path and NEITHER is saturated: `frac` is the HBM fraction of the
@@ -211,6 +231,7 @@ def report(args, sc, flat, world, backend, route, dt, kernel_ms, pipe, counts, e
         "roofline": {"bound": "hbm",
                      "kernel": "K1w pipeline pass (wf_main + wf_prefix + wf_trav per segment, wf_reduce)" if wavefront else "single-launch kernel",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": frac,
+                     "frac_x2_corrected": (frac if pmc is not None else None), "frac_raw_counters": frac_raw,
                      "valu_issue_frac": valu_issue, "valu_lane_frac": valu_lane, "valu_kernel": dom,
                      "binding": "the vector-ALU issue port with partly filled waves: the kernels issue at 0.5-0.75 of the VALU rate with 37-52 "
                                 "of 64 lanes live (a third of the walkers' wave time is ready-but-not-issued); HBM carries the path state at "
@@ -252,17 +273,18 @@ def run_in_process(args):
     m = MultiContext(args.gpus)            # fails loudly (MI_ERR_INVALID: device out of range) when the node has fewer devices
     try:
         m.upload(flat)                     # scene resident in HBM (replicated) before the timed region
-        m.reserve(cam)
+        msb = int(args.max_state_gb * 1e9)
+        m.reserve(cam, msb)
         dev0 = m.context(0)
         for _ in range(args.warmup):
-            m.render(cam, seed=1, want_f32=False, want_u8=False, variant=args.variant, flags=args.flags)
+            m.render(cam, seed=1, want_f32=False, want_u8=False, variant=args.variant, flags=args.flags, max_state_bytes=msb)
         pipe = {"wf_main_ms": 0.0, "wf_trav_ms": 0.0, "wf_reduce_ms": 0.0, "launches": 0, "wf_trav_f_ms": 0.0, "wf_replay_ms": 0.0, "wf_main_a_ms": 0.0}
         counts, kms, wall = None, [], []
         # mi_multi_render is blocking: it returns after every device's stream has drained (the barrier + synchronize of the
         # contract are inside the call, on both sides of every step)
         t0 = time.perf_counter()
         for s in range(args.steps):
-            _, _, _, st = m.render(cam, seed=1 + s, want_f32=False, want_u8=False, variant=args.variant, flags=args.flags)
+            _, _, _, st = m.render(cam, seed=1 + s, want_f32=False, want_u8=False, variant=args.variant, flags=args.flags, max_state_bytes=msb)
             kms.append(st.kernel_ms)       # the slowest device's pipeline pass
             wall.append(st.total_ms)
             for k, v in dev0.last_pipeline_ms().items():
@@ -285,6 +307,7 @@ def main():
     ap.add_argument("--spp", type=int, default=0, help="override samples per pixel (debug; invalidates the metric)")
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--flags", type=int, default=0, help="mi_render_opts.flags (MI_OPT_*), developer A/B")
+    ap.add_argument("--max-state-gb", type=float, default=0.0, help="mi_render_opts.max_state_bytes in GB (0 = the library's default budget)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--via-multi", action="store_true", help="N = 1 through mi_multi_* as well (the route every N > 1 run without a launcher takes)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
@@ -327,7 +350,8 @@ def main():
     flat = sc.flatten()
     ctx = Context(local_rank)
     ctx.upload(flat)                      # scene resident in HBM before the timed region
-    r = TiledRenderer(ctx, cam, rank=rank, world=world, device=str(device), variant=args.variant, flags=args.flags)
+    r = TiledRenderer(ctx, cam, rank=rank, world=world, device=str(device), variant=args.variant, flags=args.flags,
+                      max_state_bytes=int(args.max_state_gb * 1e9))
 
     def barrier():
         if world > 1:

@@ -682,7 +682,25 @@ extern "C" int mi_scene_upload(mi_ctx* c, const mi_scene_desc* d) {
             }
         }
     }
-    // one blob: objects | list | materials | meshes | nodes | tris | attrs | textures | texels
+    // shading records, one per Scene.objects entry (pt_device.h DShade): kind + the geometry words resolve_hit reads + the material inline
+    std::vector<DShade> shade(objs.size());
+    for (size_t i = 0; i < objs.size(); i++) {
+        const DObject& O = objs[i];
+        DShade& H = shade[i];
+        memset(&H, 0, sizeof H);
+        H.kind = O.kind; H.ref = O.ref; H.mat_kind = -1;
+        int mat = O.material;
+        if (O.kind == OBJ_SPHERE) { H.g[0] = O.f[0]; H.g[1] = O.f[1]; H.g[2] = O.f[2]; }
+        else if (O.kind == OBJ_TRIANGLE) { H.g[0] = O.f[9]; H.g[1] = O.f[10]; H.g[2] = O.f[11]; }
+        else if (O.kind == OBJ_PLANE) { for (int k = 0; k < 6; k++) H.g[k] = O.f[k]; }
+        else if (O.kind == OBJ_MESH) mat = live[(size_t)O.ref].material;
+        if (mat >= 0 && (size_t)mat < mats.size()) {
+            const DMaterial& M = mats[(size_t)mat];
+            H.mat_kind = M.kind; H.roughness = M.roughness; H.metallic = M.metallic; H.ior = M.ior;
+            for (int k = 0; k < 3; k++) { H.albedo[k] = M.albedo[k]; H.emission[k] = M.emission[k]; H.albedo_over_pi[k] = M.albedo_over_pi[k]; }
+        }
+    }
+    // one blob: objects | list | materials | meshes | nodes | tris | attrs | textures | texels | shade
     auto align = [](size_t x) { return (x + 255) & ~(size_t)255; };
     size_t off_obj = 0;
     size_t off_list = align(off_obj + objs.size() * sizeof(DObject));
@@ -700,7 +718,8 @@ extern "C" int mi_scene_upload(mi_ctx* c, const mi_scene_desc* d) {
     size_t off_attr = align(off_tris + tris.size() * 4);
     size_t off_tex = align(off_attr + attrs.size() * sizeof(DTriAttr));
     size_t off_texel = align(off_tex + texs.size() * sizeof(DTexture));
-    size_t total = align(off_texel + texels.size() + 16);
+    size_t off_shade = align(off_texel + texels.size() + 16);
+    size_t total = align(off_shade + (shade.size() + 1) * sizeof(DShade));
     if (total > 0xffffffffull) return fail(MI_ERR_UNSUPPORTED, "scene larger than 4 GiB");
     std::vector<uint8_t> host(total, 0);
     auto put = [&](size_t off, const void* p, size_t n) { if (n) memcpy(host.data() + off, p, n); };
@@ -720,6 +739,7 @@ extern "C" int mi_scene_upload(mi_ctx* c, const mi_scene_desc* d) {
     put(off_attr, attrs.data(), attrs.size() * sizeof(DTriAttr));
     put(off_tex, texs.data(), texs.size() * sizeof(DTexture));
     put(off_texel, texels.data(), texels.size());
+    put(off_shade, shade.data(), shade.size() * sizeof(DShade));
 
     if (c->blob) { (void)hipFree(c->blob); c->blob = nullptr; c->blob_bytes = 0; c->have_scene = false; }
     hipError_t e = hipMalloc(&c->blob, total);
@@ -728,6 +748,7 @@ extern "C" int mi_scene_upload(mi_ctx* c, const mi_scene_desc* d) {
     HIP_TRY(hipMemcpy(c->blob, host.data(), total, hipMemcpyHostToDevice));
     uint8_t* b = (uint8_t*)c->blob;
     c->S.objects = (const DObject*)(b + off_obj);
+    c->S.shade = (const DShade*)(b + off_shade);
     c->S.list = (const DObject*)(b + off_list);
     c->S.bobjs = (const DObject*)(b + off_bobj);
     c->gen_volumes = !bobjs.empty();
@@ -1196,15 +1217,26 @@ static int render_tiles_wavefront(mi_ctx* c, const K1Args& k, const mi_camera_de
 
     uint64_t counts[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
     counts[4] = (uint64_t)a.npix * (range.end - range.begin); counts[5] = a.npix;
+    // samples of dead tiles (nothing reachable from the tile: no ray is generated, no slot written or read) — only without signatures
+    if (a.tile_mask && !d_sig) {
+        uint64_t dead_px = 0;
+        for (uint32_t t = (uint32_t)a.R.rank; t < a.R.tiles_total; t += (uint32_t)a.R.world) {
+            if (!(c->h_tile_mask[(size_t)a.R.tiles_total + t] >> 63)) continue;
+            const uint32_t x0 = (t % a.R.tiles_x) * MI_TILE, y0 = (t / a.R.tiles_x) * MI_TILE;
+            if (x0 >= cam->screen_width || y0 >= cam->screen_height) continue;
+            dead_px += (uint64_t)std::min<uint32_t>(MI_TILE, cam->screen_width - x0) * std::min<uint32_t>(MI_TILE, cam->screen_height - y0);
+        }
+        counts[7] = dead_px * (range.end - range.begin);
+    }
     const bool have_walkers = ref_mask || ts_mask || c->S.n_meshes > 32;
     // Headers: wf_prefix stores {blocks, live paths, queue length, seq, class-B paths, class-A blocks} of every pass into a RING of
     // pinned host slots (slot = seq % kHdrRing), so the host may run a few passes ahead of the device and still read every header.
-    struct PassHdr { uint32_t blocks, live, queue, live_b, blocks_a; };
+    struct PassHdr { uint32_t blocks, live, queue, live_b, blocks_a, segments; };
     auto header_ready = [&](uint32_t seq) { return ((volatile uint32_t*)c->h_hdr)[(size_t)(seq % kHdrRing) * 8 + 3] == seq; };
     auto read_header = [&](uint32_t seq) {
         __atomic_thread_fence(__ATOMIC_ACQUIRE);
         const volatile uint32_t* h = (volatile uint32_t*)c->h_hdr + (size_t)(seq % kHdrRing) * 8;
-        PassHdr r = { h[0], h[1], h[2], h[4], h[5] };
+        PassHdr r = { h[0], h[1], h[2], h[4], h[5], h[6] };
         return r;
     };
     auto wait_header = [&](uint32_t seq) -> int {
@@ -1239,12 +1271,13 @@ static int render_tiles_wavefront(mi_ctx* c, const K1Args& k, const mi_camera_de
         HIP_TRY(hipMemsetAsync(cnt, 0, (3 * S_ + 8) * sizeof(uint32_t), stream));   // wf_prefix re-zeroes them after every pass
         const uint32_t seq0 = c->hdr_seq + 1u;          // seq of this batch's pass 0
         uint32_t seen = 0;                              // headers of passes [0, seen) have been read
-        PassHdr last = { (a.n_in + kBlock - 1) / kBlock, a.n_in, 0u, 0u, 0u };      // "header of pass -1": the camera rays
+        PassHdr last = { (a.n_in + kBlock - 1) / kBlock, a.n_in, 0u, 0u, 0u, 0u };      // "header of pass -1": the camera rays
         bool all_dead = false;
         auto consume = [&](bool count_it) {             // read header `seen` (it has arrived)
             last = read_header(seq0 + seen);
             seen++;
             if (count_it) { counts[0] += 1; counts[1] += last.live - last.live_b; counts[2] += last.live_b; counts[3] += last.queue; }
+            counts[6] += last.segments;                 // every launched pass counts: a pass behind the one that ended every path ran no segment
             if (last.live == 0) all_dead = true;
         };
         uint32_t it = 0;

@@ -90,6 +90,27 @@
 #ifndef PT_TRAVI_LEAF2
 #define PT_TRAVI_LEAF2 1    // wf_trav_i: a leaf step tests a second triangle when at least this many lanes sit on a leaf again (end of round 3, cfg4 walker: 24 / 16 / 8 / 4 / 1 -> 192.8 / 189.6 / 186.1 / 187.4 / 186.6 ms)
 #endif
+#ifndef PT_PRE_ATTR
+#define PT_PRE_ATTR 1       // walkers leave {attribute-record index, mesh index} of a mesh hit in the spare words of its plane-5 record: resolve_hit then
+                            // fetches the mesh record and the triangle's attributes side by side instead of entry -> mesh -> attributes; 0 for A/B
+#endif
+#ifndef PT_SHADE_RECORD
+#define PT_SHADE_RECORD 0   // (1 =) resolve_hit reads ONE 96-byte record per pending hit (DShade: kind, geometry words, material inline) instead of
+                            // objects[i] and then materials[objects[i].material]: one gather hop fewer in front of every shade; 0 for A/B
+#endif
+#ifndef PT_SPHERE_STAGED
+#define PT_SPHERE_STAGED 1  // list Spheres in two stages (sphere_stage1 / sphere_finish); 0 = one full test per sphere, for A/B
+#endif
+#ifndef PT_SEG_COUNT
+#define PT_SEG_COUNT 1      // wf_main counts its path segments (mi_last_pipeline_counts[6]); 0 only to measure what the count costs
+#endif
+#ifndef PT_LDS_PLANAR
+#define PT_LDS_PLANAR 0     // 1 = walkers' LDS node image in two planes — all first halves (box min + skip link), then all second halves (box max + leaf word) —
+                            // instead of node by node: a 16-byte read of node i then starts at bank 4 i mod 64 (sixteen distinct bank quads) where the
+                            // interleaved image's 32-byte stride reaches only eight, so sixteen lanes on sixteen nodes need not collide.  Same values.
+                            // MEASURED NEGATIVE (round 4, A/B on one box, walker ms planar vs interleaved): cfg2 25.3 / 25.1 vs 25.0 / 24.8, cfg4 189.9 / 190.7
+                            // vs 184.9 / 184.8, HEAD 35.8 / 36.3 vs 34.8 / 35.1 — the interleaved image stays (PMC conflict counters there)
+#endif
 #ifndef PT_TRAV_PEND
 #define PT_TRAV_PEND 16    // walkers over several meshes: lanes that have finished one mesh wait until this many can take the next root tests together (HEAD walker: 4 / 8 / 16 / 24 -> 40.9 / 38.1 / 36.3 / 37.0 ms; on the spot: 43.4)
 #endif
@@ -439,7 +460,12 @@ struct Bvh {
 struct BvhNodesLds {
     const float4* nodes;
     cf4_ptr tris;
+    int plane;             // PT_LDS_PLANAR: nodes staged (the second plane starts there)
+#if PT_LDS_PLANAR
+    __device__ __forceinline__ void node(int i, float4& n0, float4& n1) const { n0 = nodes[i]; n1 = nodes[plane + i]; }
+#else
     __device__ __forceinline__ void node(int i, float4& n0, float4& n1) const { n0 = nodes[2 * i]; n1 = nodes[2 * i + 1]; }
+#endif
     __device__ __forceinline__ void tri(int i, f3& a, f3& e1, f3& e2) const {
         float4 t0 = tris[3 * i], t1 = tris[3 * i + 1], t2 = tris[3 * i + 2];
         a = mk3(t0.x, t0.y, t0.z); e1 = mk3(t1.x, t1.y, t1.z); e2 = mk3(t2.x, t2.y, t2.z);
@@ -528,6 +554,14 @@ __device__ __forceinline__ void load_material(const DScene& S, int id, Surf& s) 
     s.roughness = m->roughness; s.metallic = m->metallic; s.ior = m->ior;
 }
 
+// the material of a Scene.objects entry from its shading record (pt_device.h DShade): same values, one gather
+template <class SP> __device__ __forceinline__ void load_material_inline(SP h, Surf& s) {
+    s.kind = h->mat_kind;
+    s.albedo = ld3(h->albedo); s.emission = ld3(h->emission);
+    s.brdf_diffuse = ld3(h->albedo_over_pi);
+    s.roughness = h->roughness; s.metallic = h->metallic; s.ior = h->ior;
+}
+
 // RayHit::new (tracing.rs:121-133): face the normal against the ray
 __device__ __forceinline__ void face(f3 normal, f3 dir, f3& n_out, bool& frontface) {
     frontface = dot(normal, dir) < 0.0f;
@@ -539,16 +573,26 @@ __device__ __forceinline__ void face(f3 normal, f3 dir, f3& n_out, bool& frontfa
 // MESH = 0 compiles the mesh branch out: for launches whose pending hits cannot be mesh hits (wf_main's camera-ray pass and
 // its class-A parts: a mesh hit only ever comes back from a walker, into class B).  MESH = 1: every mesh of the scene has a fixed
 // material and no normal map (cfg2's teapot), so texel fetches, the material-from-maps branch and the TBN are compiled out.  2: all.
+// pre_mesh / pre_attr (wavefront pipeline, PT_PRE_ATTR): the walker that found a mesh hit knows its mesh and has the mesh's first
+// triangle in registers, so it leaves {mesh index, index of the triangle's DTriAttr} in the spare words of the hit's plane-5 record.
+// With them the mesh record and the attribute record are fetched SIDE BY SIDE as soon as the path state has arrived, instead of
+// entry -> mesh -> attributes one gather after the other (-1: not provided, the chain is followed as before).
 template <int MESH = 2>
-__device__ __forceinline__ void resolve_hit(const DScene& S, const Best& b, f3 o, f3 d, Surf& s) {
+__device__ __forceinline__ void resolve_hit(const DScene& S, const Best& b, f3 o, f3 d, Surf& s, int pre_mesh = -1, int pre_attr = -1) {
+#if PT_SHADE_RECORD
+    auto ob = &S.shade[b.obj];
+#else
     auto ob = &S.objects[b.obj];
+#endif
     int kind = ob->kind;
-    if (MESH && kind == OBJ_MESH) {
-        auto M = &S.meshes[ob->ref];
+    if (MESH && (PT_PRE_ATTR ? b.tri >= 0 : kind == OBJ_MESH)) {         // Best.tri >= 0 <=> the pending hit is a mesh triangle (list hits carry tags < 0)
+        int mesh_idx = pre_mesh, attr_idx = pre_attr;
+        if (!PT_PRE_ATTR || mesh_idx < 0) { mesh_idx = ob->ref; attr_idx = S.meshes[mesh_idx].tri_begin + b.tri; }
+        auto M = &S.meshes[mesh_idx];
         // geometry.rs:304 — object-space ray (direction NOT renormalised)
         f3 oo = xform_point(M->inv_transform, o);
         f3 od = xform_vector(M->inv_transform, d);
-        auto A = &S.triattr[M->tri_begin + b.tri];
+        auto A = &S.triattr[attr_idx];
         float u = b.u, v = b.v, w = (1.0f - u - v);
         // geometry.rs:351 normalize(u*nb + v*nc + (1-u-v)*na)
         f3 mesh_normal = normalize((ld3(A->nb) * u + ld3(A->nc) * v) + ld3(A->na) * w);
@@ -583,7 +627,11 @@ __device__ __forceinline__ void resolve_hit(const DScene& S, const Best& b, f3 o
         s.n = normalize(xform_vector_transposed(M->inv_transform, n));   // :297
         s.frontface = ff;
         if (MESH != 2 || M->material >= 0) {
+#if PT_SHADE_RECORD
+            load_material_inline(ob, s);                                 // :255-256 (the mesh's fixed material, inline in its entry's record)
+#else
             load_material(S, M->material, s);                            // :255-256
+#endif
         } else {                                                         // :259-269
             s.kind = MAT_PARAMETERIZED;
             if (have_comb) {        // absent maps were filled with their defaults' bytes (0, 0, 0, 255): same values
@@ -601,18 +649,26 @@ __device__ __forceinline__ void resolve_hit(const DScene& S, const Best& b, f3 o
         }
         return;
     }
+#if PT_SHADE_RECORD
+    load_material_inline(ob, s);
+    const PT_CONST_AS float* gf = ob->g;          // Sphere centre | Triangle normal | Plane point, normal
+    const int tri_n = 0;
+#else
     load_material(S, ob->material, s);
+    const PT_CONST_AS float* gf = ob->f;
+    const int tri_n = 9;
+#endif
     f3 hp = o + d * b.t;                                                 // tracing.rs:125
     s.p = hp;
     if (kind == OBJ_SPHERE) {
-        f3 c = ld3(ob->f);
+        f3 c = ld3(gf);
         face(normalize(hp - c), d, s.n, s.frontface);                    // geometry.rs:411
     } else if (kind == OBJ_TRIANGLE) {
-        face(ld3(ob->f + 9), d, s.n, s.frontface);                       // geometry.rs:449
+        face(ld3(gf + tri_n), d, s.n, s.frontface);                      // geometry.rs:449
     } else if (kind == OBJ_PLANE) {
         // geometry.rs:476-478,487: n = signum(origin_dist) * normal
-        f3 normal = ld3(ob->f + 3);
-        float origin_dist = dot(o - ld3(ob->f), normal);
+        f3 normal = ld3(gf + 3);
+        float origin_dist = dot(o - ld3(gf), normal);
         float sg = (origin_dist != origin_dist) ? origin_dist : (__float_as_uint(origin_dist) >> 31 ? -1.0f : 1.0f);
         face(normal * sg, d, s.n, s.frontface);
     } else {                                                             // OBJ_VOLUME geometry.rs:520
@@ -718,6 +774,36 @@ __device__ __forceinline__ void consider_list(Best& b, bool& have, bool ok, floa
     b.obj = take ? obj : b.obj;
     b.tri = take ? tag : b.tri;
 }
+// Sphere::intersect_ray (geometry.rs:395-413) over a run of Sphere entries, in TWO STAGES — the cull over Scene.objects for
+// incoherent rays.  The test's cheap head is the discriminant (18 VALU: f, b, c, d = b*b - 4*a*c) and its first
+// exit is `if d < 0.0 { None }` (:402); the tail — a correctly rounded sqrt and two divisions, the root choice, the range test,
+// ~40 VALU — is only ever needed by a lane whose ray passed that exit, and a bounce ray passes it for few of a scene's spheres.
+// So stage 1 runs for every sphere (wave-uniform record in SGPRs) and a lane that passes KEEPS {b, d, index} in a one-entry stash;
+// stage 2 runs for the stashed lanes when some lane is about to need its stash again, and once at the end: as often as the
+// fullest lane has candidates (2-3 times for the 17 spheres of run()'s scene) instead of once per sphere.  Exact by construction,
+// no error bound involved: every value is computed by the reference's operations on the reference's operands, a lane's
+// candidates reach `consider_list` in list order, and a lane that is no candidate was rejected by the reference's own comparison
+// (a NaN discriminant is not `< 0.0`: it stays a candidate and "hits" at NaN as it does in the reference).
+struct SphereStash { float b, disc; int idx; bool full; };
+__device__ __forceinline__ void sphere_finish(SphereStash& st, float two_a, float t_min, float t_max, Best& best, bool& have) {
+    const float sq = sqrtf(st.disc);                                     // NaN for a NaN discriminant (never negative here)
+    const float t1 = (-st.b - sq) / two_a, t2 = (-st.b + sq) / two_a;     // :405-406
+    const float t = (t1 >= t_min) ? t1 : t2;                              // :407
+    const bool ok = st.full & !((t < t_min) | (t > t_max));               // :409
+    consider_list(best, have, ok, t, st.idx, -2);
+    st.full = false;
+}
+template <class REC>
+__device__ __forceinline__ void sphere_stage1(REC ob, f3 o, f3 d, float a, float two_a, float t_min, float t_max, SphereStash& st, Best& best, bool& have) {
+    const f3 f = o - ld3(ob->f);                                          // :397
+    const float b = 2.0f * dot(f, d);                                     // :399
+    const float c = mag2(f) - ob->f[4];                                   // :400, f[4] = radius * radius (hoisted: same product)
+    const float disc = b * b - 4.0f * a * c;                              // :401
+    const bool cand = !(disc < 0.0f);                                     // :402
+    if (__builtin_amdgcn_ballot_w64(cand & st.full) != 0ull) sphere_finish(st, two_a, t_min, t_max, best, have);
+    st.b = cand ? b : st.b; st.disc = cand ? disc : st.disc; st.idx = cand ? ob->index : st.idx; st.full = st.full | cand;
+}
+
 // RARE = false compiles the Plane / ConvexVolume loop out (a scene without either: the Cornell configurations)
 template <bool GV = true, bool RARE = true>
 __device__ __forceinline__ void intersect_list(const DScene& S, f3 o, f3 d, float t_min, float t_max, Rng& rng, Best& best) {
@@ -747,14 +833,23 @@ __device__ __forceinline__ void intersect_list(const DScene& S, f3 o, f3 d, floa
             consider_list(best, have, ok0, t0, r0->index, -1);
         }
     }
-    {   // Sphere::intersect_ray geometry.rs:395-413
+    {   // Sphere::intersect_ray geometry.rs:395-413, staged (above)
         const int end = k + S.n_list_sphere;
+#if PT_SPHERE_STAGED
+        if (k < end) {
+            const float a = mag2(d), two_a = 2.0f * a;                    // :398, and the divisor of :405-406
+            SphereStash st = { 0.0f, 0.0f, -1, false };
+            for (; k < end; k++) sphere_stage1(&L[k], o, d, a, two_a, t_min, t_max, st, best, have);
+            if (__builtin_amdgcn_ballot_w64(st.full) != 0ull) sphere_finish(st, two_a, t_min, t_max, best, have);
+        }
+#else
         for (; k < end; k++) {
             auto ob = &L[k];
             float t;
             bool ok = sphere_t(o, d, ld3(ob->f), ob->f[4], t_min, t_max, t);
             consider_list(best, have, ok, t, ob->index, -2);
         }
+#endif
     }
     if (RARE) {   // Plane (geometry.rs:474-489) and ConvexVolume (geometry.rs:502-526): rare kinds, generic code
         const int end = k + S.n_list_plane + S.n_list_volume;
@@ -1519,13 +1614,14 @@ __global__ __launch_bounds__(kBlock, (MESH == 2 ? PT_MAIN_WAVES : (MESH == 1 ? P
 
 #ifdef PT_WF_STAMPS
 #define WF_STAMP(k) do { __builtin_amdgcn_s_waitcnt(0); stamp[k] = __builtin_amdgcn_s_memtime(); } while (0)
-    unsigned long long stamp[7] = {0, 0, 0, 0, 0, 0, 0};
+    unsigned long long stamp[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     WF_STAMP(0);
 #else
 #define WF_STAMP(k) do { } while (0)
 #endif
     Path P; Best best;
     uint32_t pix = 0, sample = 0;
+    int pre_mesh = -1, pre_attr = -1;
     bool alive;
     // camera rays: what can this block's tile reach at all?  (all 256 paths of a block belong to one tile:
     // 1024 | npix, 256 | 1024, so both words are wave-uniform and stay in SGPRs)
@@ -1609,6 +1705,7 @@ __global__ __launch_bounds__(kBlock, (MESH == 2 ? PT_MAIN_WAVES : (MESH == 1 ? P
         if (MESH && valid && best.tri >= 0) {       // plane 5 (barycentrics) exists only for mesh hits
             const float4 q5 = A.st_in[st_idx(5, k, cap)];
             best.u = q5.x; best.v = q5.y;
+            pre_attr = __float_as_int(q5.z); pre_mesh = __float_as_int(q5.w);       // from the walker (resolve_hit), or -1
         }
         WF_STAMP(2);
     }
@@ -1626,6 +1723,7 @@ __global__ __launch_bounds__(kBlock, (MESH == 2 ? PT_MAIN_WAVES : (MESH == 1 ? P
     int tm = 0;
     uint32_t fuse_left = A.fuse_max;
     if (ITER0) { best.obj = -1; best.t = 0.0f; best.tri = -1; best.u = best.v = 0.0f; }
+    uint32_t n_seg = 0;                          // wave-uniform: Scene::intersect_ray evaluations (path segments) of this wave
     for (;;) {
         if (pending) {
             bool end_path;
@@ -1635,7 +1733,9 @@ __global__ __launch_bounds__(kBlock, (MESH == 2 ? PT_MAIN_WAVES : (MESH == 1 ? P
             } else {
                 if (SIG) P.sig = sig_hit(P.sig, best.t, best.obj);
                 Surf s;
-                resolve_hit<MESH>(S, best, P.o, P.d, s);
+                resolve_hit<MESH>(S, best, P.o, P.d, s, pre_mesh, pre_attr);
+                pre_mesh = -1; pre_attr = -1;                                 // a hit found inside this launch is never a mesh hit
+                if (first) WF_STAMP(7);
                 P.L = mk3(P.L.x + P.T.x * s.emission.x, P.L.y + P.T.y * s.emission.y, P.L.z + P.T.z * s.emission.z);
                 P.depth++;
                 if (P.depth >= C.path_depth) {
@@ -1655,15 +1755,21 @@ __global__ __launch_bounds__(kBlock, (MESH == 2 ? PT_MAIN_WAVES : (MESH == 1 ? P
             }
             need = alive;
             pending = false;
+            if (first) WF_STAMP(8);
         }
         // ---- Scene::intersect_ray for the new ray: object list, then the mesh roots ----
+#if PT_SEG_COUNT
+        n_seg += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(need));
+#endif
         if (need) {
             tm = 0; enters = false;
             best.obj = -1; best.t = 0.0f; best.tri = -1; best.u = best.v = 0.0f;
             if (first && ITER0 && A.tile_mask) intersect_list_masked<GV, RARE>(S, list_mask, P.o, P.d, t_min, t_max, P.rng, best);
             else intersect_list<GV, RARE>(S, P.o, P.d, t_min, t_max, P.rng, best);
+            if (first) WF_STAMP(9);
             f3 oo, od, inv; int ti, tend, ttb;
             enters = enter_next_mesh(S, B, tm, P.o, P.d, t_min, t_max, oo, od, inv, ti, tend, ttb, first ? (uint32_t)mesh_word : 0xffffffffu);
+            if (first) WF_STAMP(10);
             // A ray that hits no object and enters no mesh ends its path at the next shade_ray level
             // (tracing.rs:306, background = 0).  Do that level now — same operations, same RNG state —
             // instead of streaming the path through HBM once more just to terminate it.
@@ -1694,10 +1800,12 @@ __global__ __launch_bounds__(kBlock, (MESH == 2 ? PT_MAIN_WAVES : (MESH == 1 ? P
     {
         const unsigned long long ma = __builtin_amdgcn_ballot_w64(cls_a), mb = __builtin_amdgcn_ballot_w64(cls_b2);
         const uint32_t lane = threadIdx.x & 63;
-        uint32_t* ctr = lane == 0 ? &A.out_count[out_shard] : &A.out_count[(uint32_t)kWfShards + out_shard];
-        const uint32_t add = (uint32_t)__popcll(lane == 0 ? ma : mb);
+        // ... and lane 2 adds the wave's segment count to its shard's statistics counter in the same instruction (wf_prefix sums the
+        // shards into the pass header: mi_last_pipeline_counts[6], what bench.py's Msegments/s is computed from)
+        uint32_t* ctr = lane == 0 ? &A.out_count[out_shard] : (lane == 1 ? &A.out_count[(uint32_t)kWfShards + out_shard] : &A.trav_count[out_shard]);
+        const uint32_t add = lane == 2 ? n_seg : (uint32_t)__popcll(lane == 0 ? ma : mb);
         uint32_t base = 0;
-        if (lane < 2 && add != 0) base = atomicAdd(ctr, add);
+        if (lane < (PT_SEG_COUNT ? 3 : 2) && add != 0) base = atomicAdd(ctr, add);
         const unsigned long long below = (1ull << lane) - 1ull;
         ia = (uint32_t)__shfl((int)base, 0) + (uint32_t)__popcll(ma & below);
         ib = (uint32_t)__shfl((int)base, 1) + (uint32_t)__popcll(mb & below);
@@ -1716,12 +1824,27 @@ __global__ __launch_bounds__(kBlock, (MESH == 2 ? PT_MAIN_WAVES : (MESH == 1 ? P
     }
 #ifdef PT_WF_STAMPS
     WF_STAMP(6);       // waits for the state stores too
+#if PT_WF_STAMPS >= 2
+    // finer form, the mesh (class-B) launches only: [0..5] the six phases, [6] waves sampled, [7] whole life, then the FIRST trip of the
+    // loop split up: [8] resolve_hit, [9] emission + scatter, [10] object list, [11] mesh roots
+    if (A.diag && (PT_WF_STAMPS == 3 ? MESH == 0 : MESH != 0) && !ITER0 && (bid & 63u) == 0u && threadIdx.x == 0) {     // 3: the lean (class-A) launches instead
+        unsigned long long* d = A.diag;
+        for (int k = 0; k < 6; k++) if (stamp[k + 1] && stamp[k]) atomicAdd(&d[k], stamp[k + 1] - stamp[k]);
+        atomicAdd(&d[6], 1ull);
+        atomicAdd(&d[7], stamp[6] - stamp[0]);
+        if (stamp[7]) atomicAdd(&d[8], stamp[7] - stamp[3]);
+        if (stamp[7] && stamp[8]) atomicAdd(&d[9], stamp[8] - stamp[7]);
+        if (stamp[8] && stamp[9]) atomicAdd(&d[10], stamp[9] - stamp[8]);
+        if (stamp[9] && stamp[10]) atomicAdd(&d[11], stamp[10] - stamp[9]);
+    }
+#else
     if (A.diag && (bid & 63u) == 0u && threadIdx.x == 0) {
         unsigned long long* d = A.diag + (ITER0 ? 8 : 0);
         for (int k = 0; k < 6; k++) if (stamp[k + 1] && stamp[k]) atomicAdd(&d[k], stamp[k + 1] - stamp[k]);
         atomicAdd(&d[6], 1ull);
         atomicAdd(&d[7], stamp[6] - stamp[0]);
     }
+#endif
 #endif
 }
 
@@ -1767,7 +1890,7 @@ __device__ __forceinline__ bool wf_slot(const WfArgs& A, uint32_t blocks_a, uint
 // LDS: 0 = BVH in global memory, 2 = nodes (leaves carry a and e1 of their triangle) + the e2 vectors in LDS
 template <int LDS> struct TravBvh { typedef Bvh<false> type; };
 template <> struct TravBvh<2> { typedef BvhNodesLds type; };
-__device__ __forceinline__ void bvh_bind(BvhNodesLds& B, const DScene& S, int) { B.nodes = k1_lds; B.tris = (cf4_ptr)S.tris; }
+__device__ __forceinline__ void bvh_bind(BvhNodesLds& B, const DScene& S, int nn) { B.nodes = k1_lds; B.tris = (cf4_ptr)S.tris; B.plane = nn >> 1; }
 
 // BS: threads per block.  256 for the small-LDS modes; 1024 (one block per CU) when the node array needs most of a
 // CU's 160 KB of LDS.  (Round 3: trees of that size — the drone's 3471 nodes = 140 KB with their leaves — now take wf_trav_i below,
@@ -1805,7 +1928,11 @@ __global__ __launch_bounds__(BS, (BS == 256 ? PT_TRAV_WAVES : 4)) void wf_trav(W
         cf4_ptr gn = (cf4_ptr)S.nodes;
         cf4_ptr ge = (cf4_ptr)S.e2s;
         const int ne = (int)A.R.lds_tris;
+#if PT_LDS_PLANAR
+        for (int k = threadIdx.x; k < lds_nn; k += BS) k1_lds[(k & 1) * (lds_nn >> 1) + (k >> 1)] = gn[k];
+#else
         for (int k = threadIdx.x; k < lds_nn; k += BS) k1_lds[k] = gn[k];
+#endif
         for (int k = threadIdx.x; k < ne; k += BS) k1_lds[lds_nn + k] = ge[k];
         __syncthreads();
     }
@@ -1969,7 +2096,10 @@ __global__ __launch_bounds__(BS, (BS == 256 ? PT_TRAV_WAVES : 4)) void wf_trav(W
                         Hit2 hw; hw.t = best.t; hw.obj = best.obj;
                         *st_hit(A.st_out, pos, cap) = hw;                 // the signature has its own words: no read-modify-write
                         *st_tri(A.st_out, pos, cap) = best.tri;
-                        A.st_out[st_idx(5, pos, cap)] = make_float4(best.u, best.v, 0.0f, 0.0f);
+                        // the spare words: {index of the triangle's attribute record, mesh index} for resolve_hit — known here without a
+                        // look-up only in the single-mesh form (mesh 0, its first triangle in a register); -1 = wf_main follows the chain
+                        A.st_out[st_idx(5, pos, cap)] = make_float4(best.u, best.v, __int_as_float((!MULTI && PT_PRE_ATTR) ? tb0 + best.tri : -1),
+                                                                     __int_as_float((!MULTI && PT_PRE_ATTR) ? 0 : -1));
                     }
                     have = false;
                 }
@@ -2004,10 +2134,22 @@ __global__ __launch_bounds__(BS, 8) void wf_trav_i(WfArgs A) {
     {
         cf4_ptr gi = (cf4_ptr)S.inodes;
         const int nn = (int)A.R.lds_nodes * 2;
+#if PT_LDS_PLANAR
+        for (int k = threadIdx.x; k < nn; k += BS) k1_lds[(k & 1) * (nn >> 1) + (k >> 1)] = gi[k];
+#else
         for (int k = threadIdx.x; k < nn; k += BS) k1_lds[k] = gi[k];
+#endif
         __syncthreads();
     }
     const float4* IN = k1_lds;
+#if PT_LDS_PLANAR
+    const int ipl = (int)A.R.lds_nodes;
+#define IN0(i) IN[(i)]
+#define IN1(i) IN[ipl + (i)]
+#else
+#define IN0(i) IN[2 * (i)]
+#define IN1(i) IN[2 * (i) + 1]
+#endif
     cf4_ptr LN = (cf4_ptr)S.lnodes;
     Bvh<false> B;                                                    // mesh ROOT boxes come from the ordinary node pool (enter_next_mesh)
     bvh_bind(B, S, 0);
@@ -2030,22 +2172,22 @@ __global__ __launch_bounds__(BS, 8) void wf_trav_i(WfArgs A) {
 
     // Single-mesh form: mesh 0's record — inverse transform, root box, first node, object index — is read ONCE, here, instead of by
     // four dependent scalar loads in every refill (same values, same operations on them afterwards)
-    float m0[16]; float4 r0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), r1 = r0; int root0 = 0, obj0 = 0;
+    float m0[16]; float4 r0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), r1 = r0; int root0 = 0, obj0 = 0, tb0 = 0;
     if (!MULTI) {
         auto M = &S.meshes[0];
 #pragma unroll
         for (int k = 0; k < 16; k++) m0[k] = M->inv_transform[k];
         B.node(M->node_begin, r0, r1);
-        root0 = M->i_root; obj0 = M->object_index;
-        if (root0 >= 0) root0 = __float_as_int(IN[2 * root0 + 1].w);                 // the node a ray stands on after a passed root test
+        root0 = M->i_root; obj0 = M->object_index; tb0 = M->tri_begin;
+        if (root0 >= 0) root0 = __float_as_int(IN1(root0).w);                 // the node a ray stands on after a passed root test
     }
     // the ray has passed (or skipped, for a root that is a leaf) mesh tm's root test: stand on the first node to visit
     auto start_mesh = [&]() {
-        if (!MULTI) { id = root0; if (id >= 0) { c0 = IN[2 * id]; c1 = IN[2 * id + 1]; } tbt = t_max; tbtri = -1; tbu = tbv = 0.0f; return; }
+        if (!MULTI) { id = root0; if (id >= 0) { c0 = IN0(id); c1 = IN1(id); } tbt = t_max; tbtri = -1; tbu = tbv = 0.0f; return; }
         const int root = S.meshes[tm].i_root;
         id = root;
-        if (root >= 0) { id = __float_as_int(IN[2 * root + 1].w); }                  // root box passed with bound t_max: its left child
-        if (id >= 0) { c0 = IN[2 * id]; c1 = IN[2 * id + 1]; }
+        if (root >= 0) { id = __float_as_int(IN1(root).w); }                  // root box passed with bound t_max: its left child
+        if (id >= 0) { c0 = IN0(id); c1 = IN1(id); }
         tbt = t_max; tbtri = -1; tbu = tbv = 0.0f;
     };
 
@@ -2098,7 +2240,7 @@ __global__ __launch_bounds__(BS, 8) void wf_trav_i(WfArgs A) {
                 const bool hit = slab(mk3(c0.x, c0.y, c0.z), mk3(c1.x, c1.y, c1.z), too, tinv, t_min, tbt);      // geometry.rs:103
                 const int nxt = hit ? __float_as_int(c1.w) : __float_as_int(c0.w);
                 id = act ? nxt : id;
-                if (act & (id >= 0)) { c0 = IN[2 * id]; c1 = IN[2 * id + 1]; }
+                if (act & (id >= 0)) { c0 = IN0(id); c1 = IN1(id); }
             }
         } else {
             for (int k = 0; k < (PT_TRAVI_LEAF2 > 0 ? 2 : 1); k++) {
@@ -2112,7 +2254,7 @@ __global__ __launch_bounds__(BS, 8) void wf_trav_i(WfArgs A) {
                     const int ltri = __float_as_int(l1.w);
                     tbt = ok ? t : tbt; tbtri = ok ? ltri : tbtri; tbu = ok ? u : tbu; tbv = ok ? v : tbv;
                     id = __float_as_int(l0.w);
-                    if (id >= 0) { c0 = IN[2 * id]; c1 = IN[2 * id + 1]; }
+                    if (id >= 0) { c0 = IN0(id); c1 = IN1(id); }
                 }
             }
         }
@@ -2132,7 +2274,8 @@ __global__ __launch_bounds__(BS, 8) void wf_trav_i(WfArgs A) {
                         Hit2 hw; hw.t = best.t; hw.obj = best.obj;
                         *st_hit(A.st_out, pos, cap) = hw;
                         *st_tri(A.st_out, pos, cap) = best.tri;
-                        A.st_out[st_idx(5, pos, cap)] = make_float4(best.u, best.v, 0.0f, 0.0f);
+                        A.st_out[st_idx(5, pos, cap)] = make_float4(best.u, best.v, __int_as_float((!MULTI && PT_PRE_ATTR) ? tb0 + best.tri : -1),
+                                                                     __int_as_float((!MULTI && PT_PRE_ATTR) ? 0 : -1));      // as wf_trav
                     }
                     have = false;
                 }
@@ -2140,6 +2283,9 @@ __global__ __launch_bounds__(BS, 8) void wf_trav_i(WfArgs A) {
         }
     }
 }
+
+#undef IN0
+#undef IN1
 
 // ---------------------------------------------------------------- exact two-stage mesh traversal
 // For meshes whose file order makes the reference's index-range tree useless (obj/sphere.obj: 3800 box tests and 960
@@ -2575,7 +2721,7 @@ __global__ __launch_bounds__(256) void wf_replay(WfArgs A) {
             Hit2 hw; hw.t = best.t; hw.obj = best.obj;
             *st_hit(A.st_out, pos, cap) = hw;
             *st_tri(A.st_out, pos, cap) = best.tri;
-            A.st_out[st_idx(5, pos, cap)] = make_float4(u, v, 0.0f, 0.0f);
+            A.st_out[st_idx(5, pos, cap)] = make_float4(u, v, __int_as_float(PT_PRE_ATTR ? M->tri_begin + best.tri : -1), __int_as_float(PT_PRE_ATTR ? best_mesh : -1));
         }
         }   // active
     }
@@ -2590,12 +2736,14 @@ __global__ __launch_bounds__(256) void wf_prefix(uint32_t* __restrict__ out_coun
                                                  uint32_t* __restrict__ trav_pfx, uint32_t* __restrict__ hdr,
                                                  volatile uint32_t* host_hdr, uint32_t seq) {
     __shared__ uint32_t sc[4][256];
-    __shared__ uint32_t tot_b;
+    __shared__ uint32_t tot_b, tot_seg;
     const uint32_t t = threadIdx.x;
-    if (t == 0) tot_b = 0;
+    if (t == 0) { tot_b = 0; tot_seg = 0; }
     __syncthreads();
     const uint32_t a = out_count[t], b = out_count[kWfShards + t], q = b;   // the walkers' work list = the class-B paths
     atomicAdd(&tot_b, b);
+    atomicAdd(&tot_seg, trav_count[t]);                                     // path segments of the pass (statistics), per shard
+    trav_count[t] = 0;
     out_count[t] = 0; out_count[kWfShards + t] = 0;                         // ready for the next wf_main
     if (t < 4) trav_count[kWfShards + t] = 0;                               // trav_head[0] / [1]: the shared cursors of wf_trav / wf_trav_f; [2]: wf_filter_f's count
     in_count[t] = a; in_count[kWfShards + t] = b;
@@ -2622,6 +2770,7 @@ __global__ __launch_bounds__(256) void wf_prefix(uint32_t* __restrict__ out_coun
         // the host's copy goes straight into pinned host memory (no copy kernel that would queue behind the
         // persistent walkers): data, system-scope fence, then the sequence number the host polls
         host_hdr[0] = blocks_a + x1; host_hdr[1] = x3; host_hdr[2] = x2; host_hdr[4] = tot_b;     // [4]: class-B paths (statistics only)
+        host_hdr[6] = tot_seg;                                                                     // [6]: Scene::intersect_ray evaluations of this pass (statistics only)
         host_hdr[5] = blocks_a;                                                                    // [5]: the class-A blocks come first
         __threadfence_system();
         host_hdr[3] = seq;

@@ -156,7 +156,7 @@ class Context:
         """Path counts of the last wavefront render (mi_last_pipeline_counts), for traffic accounting."""
         out = (C.c_uint64 * 8)()
         abi.check(self._lib.mi_last_pipeline_counts(self._h, out))
-        k = ["passes", "paths_a", "paths_b", "queue_entries", "sample_slots", "pixels"]
+        k = ["passes", "paths_a", "paths_b", "queue_entries", "sample_slots", "pixels", "segments", "dead_tile_samples"]
         return dict(zip(k, [int(v) for v in out]))
 
     def last_diag(self):

@@ -296,7 +296,10 @@ int  mi_last_pipeline_ms(mi_ctx* ctx, float* out8);
 
 /* Path counts of the most recent wavefront render, for traffic accounting: out8 = { passes (wf_main launches
  * that left survivors or ended the batch), class-A paths written to (and read back from) the HBM path state summed
- * over the passes, class-B paths likewise, slots the mesh walkers went through (= the class-B paths: the walkers read those lists, there is no queue), sample slots, compact pixels, 0, 0 }.
+ * over the passes, class-B paths likewise, slots the mesh walkers went through (= the class-B paths: the walkers read those lists, there is no queue), sample slots, compact pixels,
+ * path segments (every Scene::intersect_ray evaluation, tracing.rs:305, counted on the device by wf_main), samples of dead tiles (tiles from which
+ * no camera ray can reach anything: no ray is generated for them — they are black by tracing.rs:306 — and none of the other counts includes them;
+ * 0 when signatures were asked for) }.
  * The bytes these stand for (72 B per class-A path and direction, 76 B per class-B path, ...) are in DESIGN.md. */
 int  mi_last_pipeline_counts(mi_ctx* ctx, uint64_t* out8);
 

@@ -96,6 +96,32 @@ def test_more_than_64_list_entries(gpu_ctx, orc, variant):
 
 
 @pytest.mark.parametrize("variant", VARIANTS)
+def test_spheres_that_give_a_ray_many_candidates(gpu_ctx, orc, variant):
+    """The list's Sphere tests run in two stages (pt_kernels.hip sphere_stage1 / sphere_finish: the discriminant for every
+    sphere, the roots only for the lanes that passed it, from a one-entry stash that is flushed whenever a lane needs it
+    again).  This scene makes a ray pass the discriminant of MANY spheres in a row — concentric glass shells around the eye's
+    line of sight, a cluster of overlapping spheres, the camera inside three of them — and lists the same sphere twice with
+    two materials (equal distances: the first Scene.objects entry wins, tracing.rs:335), once directly behind each other and
+    once with other spheres in between."""
+    twin = ((0.9, 1.2, 0.5), 0.55)
+    objs = scenes.cornell_walls()
+    objs.append(Sphere(*twin, Lambertian(albedo=(0.9, 0.1, 0.1), emission=(0.0, 0.0, 0.0))))
+    objs.append(Sphere(*twin, Lambertian(albedo=(0.1, 0.9, 0.1), emission=(2.0, 2.0, 2.0))))          # same sphere again: never seen
+    for r in (0.25, 0.5, 0.75, 1.0, 1.25):                                                             # concentric shells
+        objs.append(Sphere((-0.8, 2.2, 0.0), r, Dielectric(idx_of_refraction=1.0 + 0.1 * r)))
+    rng = np.random.default_rng(17)
+    for _ in range(24):                                                                                # an overlapping cluster
+        c = np.array((1.2, 3.6, -0.6)) + rng.uniform(-0.5, 0.5, 3)
+        mat = Metal(albedo=tuple(map(float, rng.uniform(0.3, 0.9, 3))), emission=(0, 0, 0), roughness=float(rng.uniform(0, 0.6))) \
+            if rng.random() < 0.5 else Lambertian(albedo=tuple(map(float, rng.uniform(0.2, 0.9, 3))), emission=(0, 0, 0))
+        objs.append(Sphere(tuple(map(float, c)), float(rng.uniform(0.3, 0.6)), mat))
+    objs.append(Sphere(*twin, Metal(albedo=(0.1, 0.1, 0.9), emission=(3.0, 0.0, 0.0), roughness=0.0)))   # the twin a third time, far down the list
+    for r in (0.6, 1.2, 2.4):                                                                          # the eye sits inside these
+        objs.append(Sphere((0.0, 2.5, 7.5), r, Dielectric(idx_of_refraction=1.3)))
+    compare(gpu_ctx, orc, Scene(camera(96, 72, 4, 8), objs), variant=variant)
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
 def test_tiny_max_trace_dist_and_camera_inside_objects(gpu_ctx, orc, variant):
     """max_trace_dist shorter than the room (most rays end as background although geometry lies ahead), the eye inside a
     glass sphere and inside a ConvexVolume (t_entr < 0: geometry.rs:501-513)."""

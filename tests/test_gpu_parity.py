@@ -73,6 +73,33 @@ def test_work_counters_equal_the_oracle(gpu_ctx, orc):
     assert d["slab_tests"] + cnt["mesh_tests"] == cnt["box_tests"]
 
 
+@pytest.mark.parametrize("name", ["config2", "config5", "head"])
+def test_wavefront_segment_counter_equals_the_oracle(gpu_ctx, orc, name):
+    """mi_last_pipeline_counts[6], the device-side count of Scene::intersect_ray evaluations bench.py's Msegments/s comes from:
+    equal to the oracle's segment count when every sample is traced (signatures on, or the tile masks off), and smaller by
+    exactly the dead tiles' samples (one segment each in the oracle: the camera ray that hits nothing) when they are skipped.
+    Through the split / fused / tail schedules of the pipeline: the count is per path, not per launch."""
+    sc = {"config2": lambda: scenes.config2(160, 90, 16, 10), "config5": lambda: scenes.config5(96, 64, 16, 12),
+          "head": lambda: scenes.head_scene(64, 48, 4, 10)}[name]()
+    flat = sc.flatten()
+    gpu_ctx.upload(flat)
+    _, _, _, cnt = orc.OracleScene(flat).render(sc.camera, seed=9, want_u8=False, want_sig=False, want_counters=True)
+    gpu_ctx.render(sc.camera, seed=9, want_u8=False, flags=abi.MI_OPT_NO_TILE_MASKS)
+    c = gpu_ctx.last_pipeline_counts()
+    assert c["segments"] == cnt["segments"] and c["dead_tile_samples"] == 0
+    gpu_ctx.render(sc.camera, seed=9, want_u8=False, want_sig=True)
+    assert gpu_ctx.last_pipeline_counts()["segments"] == cnt["segments"]
+    gpu_ctx.render(sc.camera, seed=9, want_u8=False)                      # dead tiles skipped
+    c = gpu_ctx.last_pipeline_counts()
+    assert c["segments"] + c["dead_tile_samples"] == cnt["segments"]
+    if name == "config2":
+        assert c["dead_tile_samples"] > 0                                 # the box is a square in a 16:9 frame
+    # several batches: the count is the frame's, not the last batch's
+    gpu_ctx.render(sc.camera, seed=9, want_u8=False, max_state_bytes=(2 * 6 * 16 + 16 + 72) * 1024 * 40 * 5)
+    c2 = gpu_ctx.last_pipeline_counts()
+    assert c2["segments"] + c2["dead_tile_samples"] == cnt["segments"]
+
+
 # ---- the rest of the Camera / Scene surface (SURVEY.md §8f-4): orthographic projection, Phong shading ----
 def _mode(sc, **kw):
     for k, v in kw.items():

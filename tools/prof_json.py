@@ -114,6 +114,8 @@ def main():
     traffic = {"config": cfg, "tag": tag, "source_hash": out["source_hash"],
                "kernel": "K1w pipeline: every wf_* launch of one frame",
                "hbm_bytes_per_launch": (tot_f + tot_w) or None, "fetch_bytes_corrected_x2": tot_f, "write_bytes": tot_w,
+               # the guide's x2 on FETCH_SIZE is calibrated on wide coalesced reads; per-ray gathers are not that: the raw sum is the lower bound
+               "hbm_bytes_raw_per_launch": (tot_f / 2 + tot_w) or None,
                "frame_ms_profiled": out["frame_ms_profiled"],
                "per_kernel": {k: {"ms": v["ms"], "hbm_bytes": v.get("hbm_bytes"), "hbm_GBps": v.get("hbm_GBps"),
                                   "valu_insts": v["counters"].get("SQ_INSTS_VALU"), "valu_issue_frac": v.get("valu_issue_frac"),
