@@ -104,13 +104,6 @@
 #ifndef PT_SEG_COUNT
 #define PT_SEG_COUNT 1      // wf_main counts its path segments (mi_last_pipeline_counts[6]); 0 only to measure what the count costs
 #endif
-#ifndef PT_LDS_PLANAR
-#define PT_LDS_PLANAR 0     // 1 = walkers' LDS node image in two planes — all first halves (box min + skip link), then all second halves (box max + leaf word) —
-                            // instead of node by node: a 16-byte read of node i then starts at bank 4 i mod 64 (sixteen distinct bank quads) where the
-                            // interleaved image's 32-byte stride reaches only eight, so sixteen lanes on sixteen nodes need not collide.  Same values.
-                            // MEASURED NEGATIVE (round 4, A/B on one box, walker ms planar vs interleaved): cfg2 25.3 / 25.1 vs 25.0 / 24.8, cfg4 189.9 / 190.7
-                            // vs 184.9 / 184.8, HEAD 35.8 / 36.3 vs 34.8 / 35.1 — the interleaved image stays (PMC conflict counters there)
-#endif
 #ifndef PT_TRAV_PEND
 #define PT_TRAV_PEND 16    // walkers over several meshes: lanes that have finished one mesh wait until this many can take the next root tests together (HEAD walker: 4 / 8 / 16 / 24 -> 40.9 / 38.1 / 36.3 / 37.0 ms; on the spot: 43.4)
 #endif
@@ -460,12 +453,7 @@ struct Bvh {
 struct BvhNodesLds {
     const float4* nodes;
     cf4_ptr tris;
-    int plane;             // PT_LDS_PLANAR: nodes staged (the second plane starts there)
-#if PT_LDS_PLANAR
-    __device__ __forceinline__ void node(int i, float4& n0, float4& n1) const { n0 = nodes[i]; n1 = nodes[plane + i]; }
-#else
     __device__ __forceinline__ void node(int i, float4& n0, float4& n1) const { n0 = nodes[2 * i]; n1 = nodes[2 * i + 1]; }
-#endif
     __device__ __forceinline__ void tri(int i, f3& a, f3& e1, f3& e2) const {
         float4 t0 = tris[3 * i], t1 = tris[3 * i + 1], t2 = tris[3 * i + 2];
         a = mk3(t0.x, t0.y, t0.z); e1 = mk3(t1.x, t1.y, t1.z); e2 = mk3(t2.x, t2.y, t2.z);
@@ -1890,7 +1878,7 @@ __device__ __forceinline__ bool wf_slot(const WfArgs& A, uint32_t blocks_a, uint
 // LDS: 0 = BVH in global memory, 2 = nodes (leaves carry a and e1 of their triangle) + the e2 vectors in LDS
 template <int LDS> struct TravBvh { typedef Bvh<false> type; };
 template <> struct TravBvh<2> { typedef BvhNodesLds type; };
-__device__ __forceinline__ void bvh_bind(BvhNodesLds& B, const DScene& S, int nn) { B.nodes = k1_lds; B.tris = (cf4_ptr)S.tris; B.plane = nn >> 1; }
+__device__ __forceinline__ void bvh_bind(BvhNodesLds& B, const DScene& S, int) { B.nodes = k1_lds; B.tris = (cf4_ptr)S.tris; }
 
 // BS: threads per block.  256 for the small-LDS modes; 1024 (one block per CU) when the node array needs most of a
 // CU's 160 KB of LDS.  (Round 3: trees of that size — the drone's 3471 nodes = 140 KB with their leaves — now take wf_trav_i below,
@@ -1928,11 +1916,7 @@ __global__ __launch_bounds__(BS, (BS == 256 ? PT_TRAV_WAVES : 4)) void wf_trav(W
         cf4_ptr gn = (cf4_ptr)S.nodes;
         cf4_ptr ge = (cf4_ptr)S.e2s;
         const int ne = (int)A.R.lds_tris;
-#if PT_LDS_PLANAR
-        for (int k = threadIdx.x; k < lds_nn; k += BS) k1_lds[(k & 1) * (lds_nn >> 1) + (k >> 1)] = gn[k];
-#else
         for (int k = threadIdx.x; k < lds_nn; k += BS) k1_lds[k] = gn[k];
-#endif
         for (int k = threadIdx.x; k < ne; k += BS) k1_lds[lds_nn + k] = ge[k];
         __syncthreads();
     }
@@ -2134,22 +2118,18 @@ __global__ __launch_bounds__(BS, 8) void wf_trav_i(WfArgs A) {
     {
         cf4_ptr gi = (cf4_ptr)S.inodes;
         const int nn = (int)A.R.lds_nodes * 2;
-#if PT_LDS_PLANAR
-        for (int k = threadIdx.x; k < nn; k += BS) k1_lds[(k & 1) * (nn >> 1) + (k >> 1)] = gi[k];
-#else
         for (int k = threadIdx.x; k < nn; k += BS) k1_lds[k] = gi[k];
-#endif
         __syncthreads();
     }
     const float4* IN = k1_lds;
-#if PT_LDS_PLANAR
-    const int ipl = (int)A.R.lds_nodes;
-#define IN0(i) IN[(i)]
-#define IN1(i) IN[ipl + (i)]
-#else
+    // (Round 4, measured negative: the LDS image in two planes — all first halves, then all second halves, so that a 16-byte read of
+    // node i starts at bank 4 i mod 64 and reaches all sixteen bank quads where the 32-byte stride reaches eight.  PMC, same box:
+    // SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE 0.50 -> 0.39 here and 0.52 -> 0.41 in wf_trav, LDS-busy cycles -19 %, but the second plane's
+    // address is one more VALU per node fetch (+3.7 % instructions) and the kernel got SLOWER by what the instructions cost: cfg4 184.6 ->
+    // 190.1 ms, cfg2 25.05 -> 25.90 ms, HEAD 34.8 -> 35.8 ms.  The walkers are bound by instruction issue; the conflicts are hidden
+    // behind it.  tools/experiments/r04_lds_planar.diff)
 #define IN0(i) IN[2 * (i)]
 #define IN1(i) IN[2 * (i) + 1]
-#endif
     cf4_ptr LN = (cf4_ptr)S.lnodes;
     Bvh<false> B;                                                    // mesh ROOT boxes come from the ordinary node pool (enter_next_mesh)
     bvh_bind(B, S, 0);
