@@ -682,25 +682,7 @@ extern "C" int mi_scene_upload(mi_ctx* c, const mi_scene_desc* d) {
             }
         }
     }
-    // shading records, one per Scene.objects entry (pt_device.h DShade): kind + the geometry words resolve_hit reads + the material inline
-    std::vector<DShade> shade(objs.size());
-    for (size_t i = 0; i < objs.size(); i++) {
-        const DObject& O = objs[i];
-        DShade& H = shade[i];
-        memset(&H, 0, sizeof H);
-        H.kind = O.kind; H.ref = O.ref; H.mat_kind = -1;
-        int mat = O.material;
-        if (O.kind == OBJ_SPHERE) { H.g[0] = O.f[0]; H.g[1] = O.f[1]; H.g[2] = O.f[2]; }
-        else if (O.kind == OBJ_TRIANGLE) { H.g[0] = O.f[9]; H.g[1] = O.f[10]; H.g[2] = O.f[11]; }
-        else if (O.kind == OBJ_PLANE) { for (int k = 0; k < 6; k++) H.g[k] = O.f[k]; }
-        else if (O.kind == OBJ_MESH) mat = live[(size_t)O.ref].material;
-        if (mat >= 0 && (size_t)mat < mats.size()) {
-            const DMaterial& M = mats[(size_t)mat];
-            H.mat_kind = M.kind; H.roughness = M.roughness; H.metallic = M.metallic; H.ior = M.ior;
-            for (int k = 0; k < 3; k++) { H.albedo[k] = M.albedo[k]; H.emission[k] = M.emission[k]; H.albedo_over_pi[k] = M.albedo_over_pi[k]; }
-        }
-    }
-    // one blob: objects | list | materials | meshes | nodes | tris | attrs | textures | texels | shade
+    // one blob: objects | list | materials | meshes | nodes | tris | attrs | textures | texels
     auto align = [](size_t x) { return (x + 255) & ~(size_t)255; };
     size_t off_obj = 0;
     size_t off_list = align(off_obj + objs.size() * sizeof(DObject));
@@ -718,8 +700,7 @@ extern "C" int mi_scene_upload(mi_ctx* c, const mi_scene_desc* d) {
     size_t off_attr = align(off_tris + tris.size() * 4);
     size_t off_tex = align(off_attr + attrs.size() * sizeof(DTriAttr));
     size_t off_texel = align(off_tex + texs.size() * sizeof(DTexture));
-    size_t off_shade = align(off_texel + texels.size() + 16);
-    size_t total = align(off_shade + (shade.size() + 1) * sizeof(DShade));
+    size_t total = align(off_texel + texels.size() + 16);
     if (total > 0xffffffffull) return fail(MI_ERR_UNSUPPORTED, "scene larger than 4 GiB");
     std::vector<uint8_t> host(total, 0);
     auto put = [&](size_t off, const void* p, size_t n) { if (n) memcpy(host.data() + off, p, n); };
@@ -739,7 +720,6 @@ extern "C" int mi_scene_upload(mi_ctx* c, const mi_scene_desc* d) {
     put(off_attr, attrs.data(), attrs.size() * sizeof(DTriAttr));
     put(off_tex, texs.data(), texs.size() * sizeof(DTexture));
     put(off_texel, texels.data(), texels.size());
-    put(off_shade, shade.data(), shade.size() * sizeof(DShade));
 
     if (c->blob) { (void)hipFree(c->blob); c->blob = nullptr; c->blob_bytes = 0; c->have_scene = false; }
     hipError_t e = hipMalloc(&c->blob, total);
@@ -748,7 +728,6 @@ extern "C" int mi_scene_upload(mi_ctx* c, const mi_scene_desc* d) {
     HIP_TRY(hipMemcpy(c->blob, host.data(), total, hipMemcpyHostToDevice));
     uint8_t* b = (uint8_t*)c->blob;
     c->S.objects = (const DObject*)(b + off_obj);
-    c->S.shade = (const DShade*)(b + off_shade);
     c->S.list = (const DObject*)(b + off_list);
     c->S.bobjs = (const DObject*)(b + off_bobj);
     c->gen_volumes = !bobjs.empty();

@@ -68,25 +68,6 @@ struct alignas(16) DMaterial {
 };
 static_assert(sizeof(DMaterial) == 64, "DMaterial must be 64 bytes");
 
-// What SHADING needs of one Scene.objects entry, in ONE 96-byte record (six float4): the object's kind, the few geometry words
-// resolve_hit reads (Sphere: centre; Triangle: its hoisted normal; Plane: point + normal) and the entry's MATERIAL inline — a
-// StaticMesh entry carries its fixed material here too (mat_kind = -1: the material comes from the mesh's maps).  A path's pending
-// hit is a per-lane index, so this record is a per-lane gather; reading `objects[i]` and then `materials[objects[i].material]` made
-// it two DEPENDENT gathers (phase stamps, round 4: resolve_hit = a third of a class-B wave's life, almost all of it waiting).
-// Same values as DObject / DMaterial hold (copied at upload).
-struct alignas(16) DShade {
-    int32_t kind;        // OBJ_*
-    int32_t ref;         // MESH: mesh index
-    int32_t mat_kind;    // MAT_*, -1 = from textures
-    int32_t pad0;
-    float   g[6];        // SPHERE g[0..2] centre | TRIANGLE g[0..2] normalize(e1 x e2) | PLANE g[0..2] point, g[3..5] normal
-    float   roughness, metallic;
-    float   albedo[3];   float ior;
-    float   emission[3]; float pad1;
-    float   albedo_over_pi[3]; float pad2;
-};
-static_assert(sizeof(DShade) == 96, "DShade must be 96 bytes");
-
 struct DTexture {
     uint32_t offset;     // byte offset of the RGB8 texels in the texel pool
     int32_t  width;
@@ -141,7 +122,6 @@ static_assert(sizeof(DTriAttr) == 80, "DTriAttr must be 80 bytes");
 
 struct DScene {
     const PT_CONST_AS DObject*   objects;
-    const PT_CONST_AS DShade*    shade;      // [n_objects], parallel to `objects`: what resolve_hit reads, one record per entry
     const PT_CONST_AS DMaterial* materials;
     const PT_CONST_AS DMesh*     meshes;
     const PT_CONST_AS float*     nodes;      // float4 pairs: {bmin.xyz, skip(int)} {bmax.xyz, tri(int, -1 = interior)}

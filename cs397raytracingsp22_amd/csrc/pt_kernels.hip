@@ -94,10 +94,6 @@
 #define PT_PRE_ATTR 1       // walkers leave {attribute-record index, mesh index} of a mesh hit in the spare words of its plane-5 record: resolve_hit then
                             // fetches the mesh record and the triangle's attributes side by side instead of entry -> mesh -> attributes; 0 for A/B
 #endif
-#ifndef PT_SHADE_RECORD
-#define PT_SHADE_RECORD 0   // (1 =) resolve_hit reads ONE 96-byte record per pending hit (DShade: kind, geometry words, material inline) instead of
-                            // objects[i] and then materials[objects[i].material]: one gather hop fewer in front of every shade; 0 for A/B
-#endif
 #ifndef PT_SPHERE_STAGED
 #define PT_SPHERE_STAGED 1  // list Spheres in two stages (sphere_stage1 / sphere_finish); 0 = one full test per sphere, for A/B
 #endif
@@ -542,14 +538,6 @@ __device__ __forceinline__ void load_material(const DScene& S, int id, Surf& s) 
     s.roughness = m->roughness; s.metallic = m->metallic; s.ior = m->ior;
 }
 
-// the material of a Scene.objects entry from its shading record (pt_device.h DShade): same values, one gather
-template <class SP> __device__ __forceinline__ void load_material_inline(SP h, Surf& s) {
-    s.kind = h->mat_kind;
-    s.albedo = ld3(h->albedo); s.emission = ld3(h->emission);
-    s.brdf_diffuse = ld3(h->albedo_over_pi);
-    s.roughness = h->roughness; s.metallic = h->metallic; s.ior = h->ior;
-}
-
 // RayHit::new (tracing.rs:121-133): face the normal against the ray
 __device__ __forceinline__ void face(f3 normal, f3 dir, f3& n_out, bool& frontface) {
     frontface = dot(normal, dir) < 0.0f;
@@ -567,11 +555,12 @@ __device__ __forceinline__ void face(f3 normal, f3 dir, f3& n_out, bool& frontfa
 // entry -> mesh -> attributes one gather after the other (-1: not provided, the chain is followed as before).
 template <int MESH = 2>
 __device__ __forceinline__ void resolve_hit(const DScene& S, const Best& b, f3 o, f3 d, Surf& s, int pre_mesh = -1, int pre_attr = -1) {
-#if PT_SHADE_RECORD
-    auto ob = &S.shade[b.obj];
-#else
+    // (Round 4, measured negative: ONE 96-byte record per entry with the material inline, so that this gather and the material's are not
+    // two dependent ones.  The phase stamps had shown resolve_hit as a third of a class-B wave's life; but a hop fewer did not help and
+    // the wider record cost: cfg4 wf_main 76.8 -> 79.9 ms, cfg2 +1 ms.  A gather's cost here is the number of distinct cache LINES the
+    // 64 lanes touch per load instruction, not the number of dependent hops: the material table is a handful of lines whichever entry a
+    // lane hit, the inline copies are one line per entry.  tools/experiments/r04_shade_record.diff.)
     auto ob = &S.objects[b.obj];
-#endif
     int kind = ob->kind;
     if (MESH && (PT_PRE_ATTR ? b.tri >= 0 : kind == OBJ_MESH)) {         // Best.tri >= 0 <=> the pending hit is a mesh triangle (list hits carry tags < 0)
         int mesh_idx = pre_mesh, attr_idx = pre_attr;
@@ -615,11 +604,7 @@ __device__ __forceinline__ void resolve_hit(const DScene& S, const Best& b, f3 o
         s.n = normalize(xform_vector_transposed(M->inv_transform, n));   // :297
         s.frontface = ff;
         if (MESH != 2 || M->material >= 0) {
-#if PT_SHADE_RECORD
-            load_material_inline(ob, s);                                 // :255-256 (the mesh's fixed material, inline in its entry's record)
-#else
             load_material(S, M->material, s);                            // :255-256
-#endif
         } else {                                                         // :259-269
             s.kind = MAT_PARAMETERIZED;
             if (have_comb) {        // absent maps were filled with their defaults' bytes (0, 0, 0, 255): same values
@@ -637,26 +622,18 @@ __device__ __forceinline__ void resolve_hit(const DScene& S, const Best& b, f3 o
         }
         return;
     }
-#if PT_SHADE_RECORD
-    load_material_inline(ob, s);
-    const PT_CONST_AS float* gf = ob->g;          // Sphere centre | Triangle normal | Plane point, normal
-    const int tri_n = 0;
-#else
     load_material(S, ob->material, s);
-    const PT_CONST_AS float* gf = ob->f;
-    const int tri_n = 9;
-#endif
     f3 hp = o + d * b.t;                                                 // tracing.rs:125
     s.p = hp;
     if (kind == OBJ_SPHERE) {
-        f3 c = ld3(gf);
+        f3 c = ld3(ob->f);
         face(normalize(hp - c), d, s.n, s.frontface);                    // geometry.rs:411
     } else if (kind == OBJ_TRIANGLE) {
-        face(ld3(gf + tri_n), d, s.n, s.frontface);                      // geometry.rs:449
+        face(ld3(ob->f + 9), d, s.n, s.frontface);                       // geometry.rs:449
     } else if (kind == OBJ_PLANE) {
         // geometry.rs:476-478,487: n = signum(origin_dist) * normal
-        f3 normal = ld3(gf + 3);
-        float origin_dist = dot(o - ld3(gf), normal);
+        f3 normal = ld3(ob->f + 3);
+        float origin_dist = dot(o - ld3(ob->f), normal);
         float sg = (origin_dist != origin_dist) ? origin_dist : (__float_as_uint(origin_dist) >> 31 ? -1.0f : 1.0f);
         face(normal * sg, d, s.n, s.frontface);
     } else {                                                             // OBJ_VOLUME geometry.rs:520
