@@ -2082,7 +2082,10 @@ __global__ __launch_bounds__(BS, (BS == 256 ? PT_TRAV_WAVES : 4)) void wf_trav(W
 // LDS-busy time and the VALU-issue time of that kernel ADDING up to its duration instead of overlapping.  Here only the INTERIOR
 // nodes live in LDS (pt_device.h DScene.inodes: half the bytes, every link explicit), so two such blocks fit a CU — 8 waves per
 // SIMD — and a leaf is three 16-byte reads from the leaf pool in global memory (L2-resident: 11 of the ~96 steps of a drone ray).
-template <int BS, bool MULTI>
+// LEAF_LDS = true (round 4): the leaf records staged in LDS as well, behind the interior ones — for trees whose WHOLE split image fits 64 KB
+// (the teapot: 7.6 + 11.5 KB, eight 256-thread blocks per CU as wf_trav<2, 256>).  Same storage cost as wf_trav's image, but the explicit
+// links make an interior step four VALU instructions shorter (no `ti < tend`, no `ti + 1`, no clamp of the prefetch behind the last node).
+template <int BS, bool MULTI, bool LEAF_LDS = false>
 __global__ __launch_bounds__(BS, 8) void wf_trav_i(WfArgs A) {
     const DScene& S = A.S;
     const uint32_t blocks_a = A.in_blkpfx[kWfShards];
@@ -2096,9 +2099,17 @@ __global__ __launch_bounds__(BS, 8) void wf_trav_i(WfArgs A) {
         cf4_ptr gi = (cf4_ptr)S.inodes;
         const int nn = (int)A.R.lds_nodes * 2;
         for (int k = threadIdx.x; k < nn; k += BS) k1_lds[k] = gi[k];
+        if (LEAF_LDS) {
+            cf4_ptr gl = (cf4_ptr)S.lnodes;
+            const int nl = (int)A.R.lds_tris * 3;                    // float4 slots of the staged leaf records
+            for (int k = threadIdx.x; k < nl; k += BS) k1_lds[nn + k] = gl[k];
+        }
+        // (Tried and dropped: links turned into LDS byte offsets while staging, so that a node fetch needs no address arithmetic — the shift
+        // was folded into the address add already: walker 23.8 -> 23.8 ms on cfg2, 190.0 -> 190.9 ms on cfg4 with its leaves' links scaled on the fly.)
         __syncthreads();
     }
     const float4* IN = k1_lds;
+    const float4* LL = k1_lds + (int)A.R.lds_nodes * 2;              // LEAF_LDS: the leaf records
     // (Round 4, measured negative: the LDS image in two planes — all first halves, then all second halves, so that a 16-byte read of
     // node i starts at bank 4 i mod 64 and reaches all sixteen bank quads where the 32-byte stride reaches eight.  PMC, same box:
     // SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE 0.50 -> 0.39 here and 0.52 -> 0.41 in wf_trav, LDS-busy cycles -19 %, but the second plane's
@@ -2205,7 +2216,9 @@ __global__ __launch_bounds__(BS, 8) void wf_trav_i(WfArgs A) {
                 if (k > 0 && __popcll(__builtin_amdgcn_ballot_w64(lf)) < PT_TRAVI_LEAF2) break;
                 if (lf) {
                     const int li = ~id;
-                    const float4 l0 = LN[3 * li], l1 = LN[3 * li + 1], l2 = LN[3 * li + 2];
+                    float4 l0, l1, l2;
+                    if (LEAF_LDS) { l0 = LL[3 * li]; l1 = LL[3 * li + 1]; l2 = LL[3 * li + 2]; }
+                    else { l0 = LN[3 * li]; l1 = LN[3 * li + 1]; l2 = LN[3 * li + 2]; }
                     float t, u, v;
                     const bool ok = tri_t(too, tod, mk3(l0.x, l0.y, l0.z), mk3(l1.x, l1.y, l1.z), mk3(l2.x, l2.y, l2.z), t_min, tbt, t, u, v);   // :97
                     const int ltri = __float_as_int(l1.w);
@@ -2905,7 +2918,12 @@ hipError_t launch_wf_trav(const WfArgs& a, uint32_t n_blocks, int lds_mode, size
     else { if (multi) hipLaunchKernelGGL((wf_trav<0, 256, true>), grid, block, 0, stream, a); else hipLaunchKernelGGL((wf_trav<0, 256, false>), grid, block, 0, stream, a); }
     return hipGetLastError();
 }
-hipError_t launch_wf_trav_i(const WfArgs& a, uint32_t n_blocks, size_t lds_bytes, bool* big_lds_enabled, hipStream_t stream) {
+hipError_t launch_wf_trav_i(const WfArgs& a, uint32_t n_blocks, size_t lds_bytes, bool leaf_lds, bool* big_lds_enabled, hipStream_t stream) {
+    if (leaf_lds) {                // the whole split image (interior + leaf records) fits 64 KB: 256-thread blocks, several per CU
+        if (a.trav_mask != 1u || a.S.n_meshes > 32) hipLaunchKernelGGL((wf_trav_i<256, true, true>), dim3(n_blocks), dim3(256), lds_bytes, stream, a);
+        else hipLaunchKernelGGL((wf_trav_i<256, false, true>), dim3(n_blocks), dim3(256), lds_bytes, stream, a);
+        return hipGetLastError();
+    }
     if (!*big_lds_enabled) {       // the attribute belongs to the function on the current device: kept per context
         hipError_t e = hipFuncSetAttribute((const void*)wf_trav_i<1024, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)wf_trav_i<1024, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
