@@ -90,6 +90,12 @@
 #ifndef PT_TRAVI_LEAF2
 #define PT_TRAVI_LEAF2 1    // wf_trav_i: a leaf step tests a second triangle when at least this many lanes sit on a leaf again (end of round 3, cfg4 walker: 24 / 16 / 8 / 4 / 1 -> 192.8 / 189.6 / 186.1 / 187.4 / 186.6 ms)
 #endif
+#ifndef PT_TRAVL_BURST
+#define PT_TRAVL_BURST 10   // wf_trav_i with the leaves in LDS too (small trees): interior steps per vote (round 4, cfg2 walker: 6 / 8 / 10 / 14 -> 25.4 / 24.6 / 24.0 / 25.1 ms)
+#endif
+#ifndef PT_TRAVL_LEAF2
+#define PT_TRAVL_LEAF2 1    // ... and the second triangle of a leaf step, taken when at least this many lanes sit on a leaf again (0 = never / 1 / 16 -> 24.9 / 24.0 / 24.2 ms)
+#endif
 #ifndef PT_PRE_ATTR
 #define PT_PRE_ATTR 1       // walkers leave {attribute-record index, mesh index} of a mesh hit in the spare words of its plane-5 record: resolve_hit then
                             // fetches the mesh record and the triangle's attributes side by side instead of entry -> mesh -> attributes; 0 for A/B
@@ -2203,7 +2209,7 @@ __global__ __launch_bounds__(BS, 8) void wf_trav_i(WfArgs A) {
         const int n_inner = __popcll(__builtin_amdgcn_ballot_w64(at_inner));
         if (n_inner >= n_leaf * PT_TRAVI_LEAF_W) {
 #pragma unroll
-            for (int j = 0; j < PT_TRAVI_BURST; j++) {
+            for (int j = 0; j < (LEAF_LDS ? PT_TRAVL_BURST : PT_TRAVI_BURST); j++) {
                 const bool act = have & (id >= 0);
                 const bool hit = slab(mk3(c0.x, c0.y, c0.z), mk3(c1.x, c1.y, c1.z), too, tinv, t_min, tbt);      // geometry.rs:103
                 const int nxt = hit ? __float_as_int(c1.w) : __float_as_int(c0.w);
@@ -2211,9 +2217,9 @@ __global__ __launch_bounds__(BS, 8) void wf_trav_i(WfArgs A) {
                 if (act & (id >= 0)) { c0 = IN0(id); c1 = IN1(id); }
             }
         } else {
-            for (int k = 0; k < (PT_TRAVI_LEAF2 > 0 ? 2 : 1); k++) {
+            for (int k = 0; k < ((LEAF_LDS ? PT_TRAVL_LEAF2 : PT_TRAVI_LEAF2) > 0 ? 2 : 1); k++) {
                 const bool lf = have & (id < 0) & (id != kIdEnd);
-                if (k > 0 && __popcll(__builtin_amdgcn_ballot_w64(lf)) < PT_TRAVI_LEAF2) break;
+                if (k > 0 && __popcll(__builtin_amdgcn_ballot_w64(lf)) < (LEAF_LDS ? PT_TRAVL_LEAF2 : PT_TRAVI_LEAF2)) break;
                 if (lf) {
                     const int li = ~id;
                     float4 l0, l1, l2;
