@@ -270,7 +270,10 @@ def run_in_process(args):
         sc.camera.aa_sample_count = args.spp
     cam = sc.camera
     flat = sc.flatten()
-    m = MultiContext(args.gpus)            # fails loudly (MI_ERR_INVALID: device out of range) when the node has fewer devices
+    # --loopback: the TEST transport (mi_multi_create_loopback) — every rank on device 0, event-ordered device-to-device copies instead of
+    # the RCCL pairs.  It runs mi_multi_render's N >= 2 code end to end on a one-GPU box; the ranks share the card, so `value` says what
+    # the multi-rank machinery costs on top of one rank, NOT how it scales.
+    m = MultiContext.loopback(args.gpus) if args.loopback else MultiContext(args.gpus)            # fails loudly (MI_ERR_INVALID: device out of range) when the node has fewer devices
     try:
         m.upload(flat)                     # scene resident in HBM (replicated) before the timed region
         msb = int(args.max_state_gb * 1e9)
@@ -291,7 +294,8 @@ def run_in_process(args):
                 pipe[k] += v
             counts = dev0.last_pipeline_counts()
         dt = time.perf_counter() - t0
-        report(args, sc, flat, args.gpus, "rccl (mi_multi, in-process)", "mi_multi_* in one process (native RCCL fan-in, include/mi_rt.h)",
+        report(args, sc, flat, args.gpus, "loopback test transport (all ranks on device 0: NOT a scaling figure)" if args.loopback else "rccl (mi_multi, in-process)",
+               "mi_multi_* in one process (loopback test transport)" if args.loopback else "mi_multi_* in one process (native RCCL fan-in, include/mi_rt.h)",
                dt, sum(kms) / max(1, len(kms)), pipe, counts,
                extra_config={"ranks": m.n_devices, "mi_multi_total_ms": sum(wall) / max(1, len(wall))})
     finally:
@@ -309,6 +313,7 @@ def main():
     ap.add_argument("--flags", type=int, default=0, help="mi_render_opts.flags (MI_OPT_*), developer A/B")
     ap.add_argument("--max-state-gb", type=float, default=0.0, help="mi_render_opts.max_state_bytes in GB (0 = the library's default budget)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--loopback", action="store_true", help="N ranks on device 0 through mi_multi_create_loopback (test transport; exercises the N >= 2 code, measures no scaling)")
     ap.add_argument("--via-multi", action="store_true", help="N = 1 through mi_multi_* as well (the route every N > 1 run without a launcher takes)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     ap.add_argument("--same-gpu", action="store_true", help="rehearsal: every rank uses GPU 0 (with --backend gloo)")
@@ -319,7 +324,7 @@ def main():
     # Two ways to N GPUs.  Under torch.distributed.run (WORLD_SIZE set): one process per GPU, dist.py + torch's RCCL gather.
     # Without a launcher: N > 1 (or --via-multi) runs in THIS process through mi_multi_* (native RCCL inside the library).
     launched = "WORLD_SIZE" in os.environ
-    if not launched and (args.gpus > 1 or args.via_multi):
+    if not launched and (args.gpus > 1 or args.via_multi or args.loopback):
         return run_in_process(args)
 
     import torch

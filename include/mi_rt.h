@@ -187,9 +187,10 @@ typedef struct mi_render_opts {
     int32_t  want_signature;    /* 1 = also produce per-pixel path signatures (diagnostic) */
     uint32_t flags;             /* MI_OPT_* bits, 0 = defaults                           */
     uint64_t max_state_bytes;   /* wavefront pipeline: upper bound on the HBM it may hold for path state and
-                                 * sample slots (0 = 60 % of the free HBM: a whole 1080p/256 spp frame is one 110 GB
-                                 * batch).  A smaller budget means more, smaller sample batches: same image, bit for
-                                 * bit, lower throughput (256 M / 64 M / 16 M paths per batch: 161 / 187 / 257 ms on cfg2).
+                                 * sample slots (0 = what renders the frame in ONE batch, at most 60 % of the free HBM: a
+                                 * whole 1080p / 256 spp frame is 110 GB).  A smaller budget means more, smaller sample
+                                 * batches: same image, bit for bit, lower throughput (cfg2, round 4: one batch 77.4 ms;
+                                 * 64 / 32 / 16 / 8 / 4 GB: +2 / +7 / +14 / +25 / +46 %: DESIGN.md section 4).
                                  * The smallest batch is one sample of every pixel of the rank (about 210 B per pixel, 280 B
                                  * with a two-stage mesh): a non-zero budget below that is MI_ERR_INVALID, never silently exceeded */
 } mi_render_opts;               /* 32 bytes */
@@ -283,7 +284,7 @@ int  mi_last_kernel_ms(mi_ctx* ctx, float* ms);
 /* Size and allocate the wavefront pipeline's HBM buffers (path state, sample slots) for
  * this camera with the image shared by `world` ranks, so that the first render does not pay the
  * allocation (about 110 GB for a whole 1080p / 256 spp frame on one GPU).  `max_state_bytes` as in
- * mi_render_opts (0 = 60 % of the free HBM).  Optional. */
+ * mi_render_opts (0 = the frame in one batch, at most 60 % of the free HBM).  Optional. */
 int  mi_reserve(mi_ctx* ctx, const mi_camera_desc* cam, int32_t world, uint64_t max_state_bytes);
 
 /* Wavefront pipeline (MI_VARIANT_WAVEFRONT) of the most recent render: out8 = { sum of wf_main

@@ -172,3 +172,14 @@ def test_two_contexts_from_two_threads(cfg2_ragged, head):
         for f32, u8, sig, _ in results[i]:
             assert np.array_equal(sig, refsig)
             assert np.array_equal(f32, ref32, equal_nan=True) and np.array_equal(u8, ref8)
+
+
+@pytest.mark.parametrize("n", [2, 8])
+def test_bench_in_process_route_with_loopback_ranks(n):
+    """`python bench.py --gpus N --loopback`: the in-process route of the scaling bench (mi_multi_* behind the ABI, what `python bench.py
+    --gpus N` runs with no launcher) with N ranks on this box's one device.  The line says what it is: not a scaling figure."""
+    from test_gpu_multi import _run_bench
+    out, rec = _run_bench("--gpus", str(n), "--loopback", "--steps", "2", "--warmup", "1", "--spp", "16", "--no-cpu-baseline")
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert rec["n_gpus"] == n and rec["config"]["ranks"] == n and rec["backend"].startswith("loopback test transport")
+    assert rec["value"] > 0 and rec["steps"] == 2 and rec["config"]["mi_multi_total_ms"] > 0
