@@ -25,10 +25,12 @@ struct Matrix4 {
     float m[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
     static Matrix4 from_translation(Vec3 v) { Matrix4 r; r.m[12] = v[0]; r.m[13] = v[1]; r.m[14] = v[2]; return r; }
     static Matrix4 from_scale(float s) { Matrix4 r; r.m[0] = r.m[5] = r.m[10] = s; return r; }
-    // Deg -> (sin, cos): radians in f64 rounded to f32, sine and cosine of THAT in f64 rounded to f32 — the definition of the
-    // Python mirror (cgmath.py _sc: math.radians, math.sin, math.cos), so both mirrors build the same matrices bit for bit
+    // Deg -> (sin, cos).  Radians as cgmath 0.18 converts them (`impl From<Deg<f32>> for Rad<f32>`: deg * (PI / 180 as f32), one f32
+    // product of the f32-rounded constant); sine and cosine of THAT in f64 rounded to f32, i.e. the correctly rounded f32 values —
+    // Rust's f32::sin_cos is the platform's sinf / cosf (< 1 ulp, almost always the same bits; not pinnable here).  Same definition
+    // as the Python mirror (cgmath.py _sc), so both mirrors build the same matrices bit for bit
     static void sincos_deg(float deg, float& s, float& c) {
-        const float r = (float)((double)deg * (3.14159265358979323846 / 180.0));
+        const float r = deg * (float)(3.14159265358979323846 / 180.0);
         s = (float)sin((double)r); c = (float)cos((double)r);
     }
     static Matrix4 from_angle_x(float deg) {
