@@ -14,8 +14,9 @@
 //                 compile-time forms per scene content (mesh branch, maps, rare kinds, generic volume boundaries); survivors
 //                 appended per shard in two classes (A: plain Triangle / Plane hit, nothing left to walk; B: the rest)
 //   wf_prefix     shard counters -> block tables of the next pass (also the walkers' work list) + the header for the host
-//   wf_trav       persistent walkers over the class-B blocks, the reference's tree in LDS (nodes + leaf triangles), voted steps
-//   wf_trav_i     the same walk for trees of 64 .. 150 KB: interior nodes in LDS, leaves from global memory, 2 x 1024 threads per CU
+//   wf_trav       persistent walkers over the class-B blocks, the reference's tree as a skip-link image (in LDS, or in global memory), voted steps
+//   wf_trav_i     the same walk over split pools with explicit links: interior records in LDS; the leaf records in LDS too for trees whose image
+//                 fits 64 KB (the default small-tree walker since round 4: 8 x 256 threads per CU), from global memory for 64 .. 150 KB (2 x 1024)
 //   wf_filter_f / wf_trav_f / wf_replay   exact two-stage traversal of large meshes: root-box filter -> padded SAH tree of
 //                 16-byte quantised nodes + the reference's triangle test -> replay of the reference's walk over the candidates
 //   wf_reduce     per-pixel sums in sample order (tracing.rs:232-241)
