@@ -233,9 +233,11 @@ def report(args, sc, flat, world, backend, route, dt, kernel_ms, pipe, counts, e
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": frac,
                      "frac_x2_corrected": (frac if pmc is not None else None), "frac_raw_counters": frac_raw,
                      "valu_issue_frac": valu_issue, "valu_lane_frac": valu_lane, "valu_kernel": dom,
-                     "binding": "the vector-ALU issue port with partly filled waves: the kernels issue at 0.5-0.75 of the VALU rate with 37-52 "
-                                "of 64 lanes live (a third of the walkers' wave time is ready-but-not-issued); HBM carries the path state at "
-                                "about a quarter of its peak and is not the limit (DESIGN.md section 5)",
+                     "binding": "neither roof: the walkers are bound by instruction issue on partly filled waves (0.73-0.75 of the VALU rate at 36-37 "
+                                "of 64 lanes; their time follows the instruction count one to one: DESIGN.md section 4 K2); wf_main is one third "
+                                "instruction issue (+28 % VALU per segment = +10 % time, ablation) and two thirds the latency of dependent memory "
+                                "operations - state stream, per-lane gathers, appends - that 6-8 waves per SIMD cannot cover; HBM carries the path "
+                                "state at 0.21-0.28 of its peak",
                      "traffic": traffic, "traffic_source": traffic_source,
                      "traffic_model_bytes": model_bytes, "path_counts": counts,
                      "kernel_ms": kernel_ms,
