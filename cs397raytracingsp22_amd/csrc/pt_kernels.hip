@@ -2166,10 +2166,18 @@ __global__ __launch_bounds__(BS, 8) void wf_trav_i(WfArgs A) {
         tbt = t_max; tbtri = -1; tbu = tbv = 0.0f;
     };
 
+#ifdef PT_TRAVI_STAMPS      // developer build (MI_RT_WF_STAMPS=1 tools/probe.py prints A.diag): [8] wave life, [9] cycles inside refills (s_memtime), [10] refills,
+                            // [11] rays they brought, [12] trips, [13] lanes holding a ray summed over the trips, [14] waves
+    unsigned long long ts_life = __builtin_amdgcn_s_memtime(), ts_refill = 0, n_refill = 0, n_taken = 0, n_trips = 0, n_have = 0;
+#endif
     while (true) {
         // ---- refill idle lanes (as wf_trav) ----
         unsigned long long need = __builtin_amdgcn_ballot_w64(!have);
         const uint32_t n_idle = (uint32_t)__popcll(need);
+#ifdef PT_TRAVI_STAMPS
+        __builtin_amdgcn_s_waitcnt(0); const unsigned long long ts_r0 = __builtin_amdgcn_s_memtime();
+        const bool did_refill = (n_idle >= A.refill_min || n_idle == 64u) && !drained;
+#endif
         if ((n_idle >= A.refill_min || n_idle == 64u) && !drained) {
             if (wnext == wend) {
                 uint32_t base = n_q;
@@ -2200,10 +2208,16 @@ __global__ __launch_bounds__(BS, 8) void wf_trav_i(WfArgs A) {
             }
             wnext += min(avail, n_idle);
         }
+#ifdef PT_TRAVI_STAMPS
+        if (did_refill) { __builtin_amdgcn_s_waitcnt(0); ts_refill += __builtin_amdgcn_s_memtime() - ts_r0; n_refill++; n_taken += (unsigned long long)__popcll(__builtin_amdgcn_ballot_w64(have)) - (64ull - n_idle); }
+#endif
         if (__builtin_amdgcn_ballot_w64(have) == 0ull) {
             if (drained) break;
             continue;
         }
+#ifdef PT_TRAVI_STAMPS
+        n_trips++; n_have += (unsigned long long)__popcll(__builtin_amdgcn_ballot_w64(have));
+#endif
         // ---- one voted step: a burst of interior nodes, or the leaves the lanes stand on ----
         const bool at_leaf = have & (id < 0) & (id != kIdEnd), at_inner = have & (id >= 0);
         const int n_leaf = __popcll(__builtin_amdgcn_ballot_w64(at_leaf));
@@ -2259,6 +2273,12 @@ __global__ __launch_bounds__(BS, 8) void wf_trav_i(WfArgs A) {
             }
         }
     }
+#ifdef PT_TRAVI_STAMPS
+    if (A.diag && lane == 0) {
+        atomicAdd(&A.diag[8], __builtin_amdgcn_s_memtime() - ts_life); atomicAdd(&A.diag[9], ts_refill); atomicAdd(&A.diag[10], n_refill);
+        atomicAdd(&A.diag[11], n_taken); atomicAdd(&A.diag[12], n_trips); atomicAdd(&A.diag[13], n_have); atomicAdd(&A.diag[14], 1ull);
+    }
+#endif
 }
 
 #undef IN0
