@@ -182,3 +182,44 @@ def test_bench_without_a_launcher_takes_the_in_process_route_and_fails_loudly_wi
     assert r.returncode != 0
     assert "no CPU fallback" in r.stderr and "torch.distributed.run" not in r.stderr
     assert not any(line.startswith("{") for line in r.stdout.splitlines())      # no result line was printed
+
+
+def test_bench_line_says_what_the_headline_counts(capsys):
+    """bench.report() on fixed numbers (no GPU): the ONE JSON line carries the contract's keys, the dead-tile share, the rate over the
+    pixels that see something, the segment rate from the device's own count, and the HBM fraction as a range when a committed PMC
+    profile of the same kernel sources exists."""
+    import importlib.util
+    import json
+    import types
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    from cs397raytracingsp22_amd import scenes
+    sc = scenes.config2()
+    flat = sc.flatten()
+    args = types.SimpleNamespace(steps=5, config="cfg2", variant=0, spp=0, flags=0, max_state_gb=0.0, no_cpu_baseline=True, warmup=1)
+    samples = 1920 * 1080 * 256
+    counts = {"passes": 11, "paths_a": 494431863, "paths_b": 338823571, "queue_entries": 338823571, "sample_slots": 534773760,
+              "pixels": 2088960, "segments": 1674413948, "dead_tile_samples": 212336640}
+    pipe = {"wf_main_ms": 260.0, "wf_trav_ms": 120.0, "wf_reduce_ms": 4.6, "launches": 180, "wf_trav_f_ms": 0.0, "wf_replay_ms": 0.0, "wf_main_a_ms": 240.0}
+    bench.report(args, sc, flat, 1, None, "one process, one GPU (mi_ctx_*)", 0.385, 76.8, pipe, counts)
+    rec = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in rec, key
+    assert rec["unit"] == "Msamples/s" and rec["dtype"] == "f32" and rec["vs_baseline"] is None and rec["n_gpus"] == 1
+    assert abs(rec["value"] - samples * 5 / 0.385 / 1e6) < 1e-6 * rec["value"]
+    cfg = rec["config"]
+    assert abs(cfg["dead_tile_frac"] - 212336640 / samples) < 1e-12
+    assert abs(cfg["live_pixel_msamples_per_s"] - (samples - 212336640) * 5 / 0.385 / 1e6) < 1e-6 * cfg["live_pixel_msamples_per_s"]
+    assert abs(cfg["segments_per_sample"] - 1674413948 / samples) < 1e-12 and cfg["msegments_per_s"] > rec["value"]
+    roof = rec["roofline"]
+    assert roof["bound"] == "hbm" and roof["peak"] == 8000.0 and roof["unit"] == "GB/s" and 0 < roof["frac"] <= 1
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-12 and roof["traffic"] > 0
+    if roof["frac_raw_counters"] is not None:           # a committed PMC profile of these kernel sources: the fraction is a range
+        assert roof["frac_raw_counters"] < roof["frac_x2_corrected"] == roof["frac"] and "committed rocprofv3 PMC" in roof["traffic_source"]
+    else:
+        assert "traffic model" in roof["traffic_source"]
+    # N > 1 ranks: the per-device counts are device 0's only, so the whole-frame figures derived from them are left out
+    bench.report(args, sc, flat, 8, "nccl", "one process per GPU", 0.385, 76.8, pipe, counts)
+    rec8 = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
+    assert rec8["n_gpus"] == 8 and rec8["config"]["dead_tile_frac"] is None and rec8["config"]["msegments_per_s"] is None and "cpu_baseline" not in rec8
