@@ -183,3 +183,35 @@ def test_bench_in_process_route_with_loopback_ranks(n):
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert rec["n_gpus"] == n and rec["config"]["ranks"] == n and rec["backend"].startswith("loopback test transport")
     assert rec["value"] > 0 and rec["steps"] == 2 and rec["config"]["mi_multi_total_ms"] > 0
+
+
+@pytest.mark.parametrize("case", ["voted", "recursive", "phong", "orthographic"])
+def test_loopback_other_kernels_and_camera_modes(case):
+    """The kernels that are not the wavefront pipeline go through mi_multi_render's ranks as well: the single-launch megakernel
+    (queued, never synchronising by itself), the recursive estimator (path_samples = 2), the Phong debug shader, and an
+    orthographic camera (tile masks off).  Three ranks on the one device, bit-identical to mi_render."""
+    sc = scenes.config2(150, 100, 4, 6)
+    kw = {}
+    if case == "voted":
+        kw["variant"] = abi.MI_VARIANT_VOTED
+    elif case == "recursive":
+        sc.camera.path_samples = 2
+        sc.camera.path_depth = 4
+    elif case == "phong":
+        sc.camera.shading_mode = abi.MI_SHADE_PHONG
+    else:
+        sc.camera.projection_mode = abi.MI_PROJ_ORTHOGRAPHIC
+    flat = sc.flatten()
+    one = Context(0)
+    try:
+        one.upload(flat)
+        ref32, ref8, refsig, _ = one.render(sc.camera, seed=13, want_sig=True, **kw)
+    finally:
+        one.close()
+    m = MultiContext.loopback(3)
+    try:
+        m.upload(flat)
+        f32, u8, sig, _ = m.render(sc.camera, seed=13, want_sig=True, **kw)
+    finally:
+        m.close()
+    assert np.array_equal(sig, refsig) and np.array_equal(f32, ref32, equal_nan=True) and np.array_equal(u8, ref8)
