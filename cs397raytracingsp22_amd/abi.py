@@ -25,7 +25,7 @@ MI_PROJ_ORTHOGRAPHIC, MI_PROJ_PERSPECTIVE = 0, 1
 MI_SHADE_PHONG, MI_SHADE_PATHTRACE = 0, 1
 MI_VARIANT_DEFAULT, MI_VARIANT_SIMPLE, MI_VARIANT_VOTED, MI_VARIANT_VOTED_DIAG = 0, 1, 3, 4      # 2, 5, 6: removed in ABI 3
 MI_VARIANT_WAVEFRONT, MI_VARIANT_RECURSIVE = 7, 8
-MI_OPT_NO_TILE_MASKS, MI_OPT_REFERENCE_WALK, MI_OPT_TWO_STAGE = 1, 2, 4
+MI_OPT_NO_TILE_MASKS, MI_OPT_REFERENCE_WALK, MI_OPT_TWO_STAGE, MI_OPT_NO_LIST_TREE = 1, 2, 4, 8
 
 f3 = C.c_float * 3
 f16 = C.c_float * 16

@@ -103,6 +103,7 @@ struct mi_ctx {
     bool have_scene = false;
     bool mesh_maps = false;                  // some mesh takes its material from maps or has a normal map: wf_main's MESH = 2 form
     bool gen_volumes = false;                // a ConvexVolume whose boundary is not the inline sphere: the kernels' GV forms
+    bool list_tree = false;                  // the list's Triangles sit in a top-level tree (long lists): wf_main's TOP forms
     uint32_t lds_bytes = 0;                  // bytes needed to stage nodes + tris, 0 = no meshes
     // per live mesh (Scene.objects order): end of its nodes in the node pool, does the two-stage bound apply to it at all,
     // is it walked two-stage by default (qualifies and large enough for the F-tree to pay)
@@ -648,6 +649,67 @@ extern "C" int mi_scene_upload(mi_ctx* c, const mi_scene_desc* d) {
             for (size_t i = 0; i < objs.size(); i++)
                 if (objs[i].kind == order[g]) { list.push_back(objs[i]); n_list[g]++; }
     }
+    // ---- top-level tree over the list's Triangles ("top-level BVH over Scene.objects"; long lists only) ----
+    // A list of hundreds of Triangles is hundreds of Moller-Trumbore tests per path segment.  The exact two-stage machinery of the
+    // meshes applies to them unchanged, in world space: a SAH tree over the triangles' boxes, walked per ray with the boxes padded by the
+    // proven bound on what the reference's f32 test can accept (bvh_build.hpp), and the reference's own test on the triangles of the leaves
+    // reached — a triangle whose padded box the ray misses would have failed that test, and the closest hit over the rest is
+    // order-independent (ties: the lower Scene.objects index).  The bound scales with E2 = max |e1||e2| over the tree, so the LARGE
+    // triangles (walls: 32 x the median product and more) stay in front of the list and are tested one by one; the tree needs >= 96 of
+    // the others.  A ray the bound does not cover (B > 1/2, non-finite) makes its wave test the whole list one by one.
+    int n_list_lin = n_list[0], top_meshf = -1;
+    {
+        constexpr int kTopMinTris = 96;       // measured (tools/probe_list_tree.py): 40 small triangles 0.85 x, 105: 1.1 x, 400: 1.6 x, 2000: 1.9 x of the plain loop
+        const int nt = n_list[0];
+        if (nt >= kTopMinTris) {
+            std::vector<double> prod((size_t)nt);
+            for (int k = 0; k < nt; k++) {
+                const float* f = list[(size_t)k].f;
+                prod[(size_t)k] = std::sqrt((double)f[3] * f[3] + (double)f[4] * f[4] + (double)f[5] * f[5]) * std::sqrt((double)f[6] * f[6] + (double)f[7] * f[7] + (double)f[8] * f[8]);
+            }
+            std::vector<double> sorted = prod;
+            std::nth_element(sorted.begin(), sorted.begin() + nt / 2, sorted.end());
+            const double big = 32.0 * sorted[(size_t)nt / 2];
+            // large triangles (and anything non-finite) to the front, order kept within each part (stable: ties between equal hits are decided by index anyway)
+            std::vector<DObject> front, rest;
+            for (int k = 0; k < nt; k++) ((!(prod[(size_t)k] <= big) || !std::isfinite(prod[(size_t)k])) ? front : rest).push_back(list[(size_t)k]);
+            if ((int)rest.size() >= kTopMinTris) {
+                std::vector<float> lt(rest.size() * 12, 0.0f), tn, tt;
+                for (size_t k = 0; k < rest.size(); k++) {
+                    const float* f = rest[k].f; float* T = &lt[k * 12];
+                    for (int q = 0; q < 3; q++) { T[q] = f[q]; T[4 + q] = f[3 + q]; T[8 + q] = f[6 + q]; }
+                }
+                build::FTree ft{ lt.data(), (int)rest.size(), &tn, &tt, 0, 2, {}, {}, {} };
+                const build::FConst fc = ft.run();
+                build::FQuant fq{ 1.0f, 0.0f, 0.0f, 0.0f };
+                std::vector<uint32_t> tq;
+                // (the bound's B = 7 eps E2 |d| / 1e-4 is checked per ray on the device; here only: is it finite, and below 1/2 for a unit direction at all)
+                const double b_unit = 7.0 * 5.9604645e-08 * (double)fc.E2 * 1.0e4;
+                if (std::isfinite(b_unit) && b_unit <= 0.25 && std::isfinite(fc.R) && std::isfinite(fc.L) && rest.size() < (1u << 24) &&
+                    build::fq_encode(tn.data(), tn.size() / 8, &fq, &tq)) {
+                    const int fbase = (int)(fnodes.size() / 4);
+                    for (size_t k = 0; k < tq.size(); k += 4) if (!(tq[k + 3] & 0x80000000u)) tq[k + 3] += (uint32_t)fbase;      // interior nodes: skip links into the pool
+                    for (size_t e = 0; e < tt.size() / 12; e++) {          // a leaf triangle carries its Scene.objects index where a mesh triangle carries its number
+                        int t; memcpy(&t, &tt[e * 12 + 3], 4);
+                        const int32_t idx = rest[(size_t)t].index;
+                        memcpy(&tt[e * 12 + 3], &idx, 4);
+                    }
+                    DMeshF F; memset(&F, 0, sizeof F);
+                    F.fnode_begin = fbase; F.ftri_begin = (int)(ftris.size() / 12);
+                    fnodes.insert(fnodes.end(), tq.begin(), tq.end());
+                    ftris.insert(ftris.end(), tt.begin(), tt.end());
+                    F.fnode_end = (int)(fnodes.size() / 4);
+                    F.qualifies = 1; F.E2 = fc.E2; F.L = fc.L; F.cx = fc.cx; F.cy = fc.cy; F.cz = fc.cz; F.R = fc.R;
+                    F.qs = fq.s; F.qbx = fq.bx; F.qby = fq.by; F.qbz = fq.bz;
+                    top_meshf = (int)livef.size();
+                    livef.push_back(F);
+                    n_list_lin = (int)front.size();
+                    for (size_t k = 0; k < front.size(); k++) list[k] = front[k];
+                    for (size_t k = 0; k < rest.size(); k++) list[front.size() + k] = rest[k];
+                }
+            }
+        }
+    }
     // world-space corners of the root boxes (tile masks).  The rays reach object space through inv_transform
     // (geometry.rs:304), so the corners come from ITS inverse (f64), not from `transform`; a projective
     // inv_transform or a single-triangle mesh (no root box) is never culled.
@@ -735,6 +797,7 @@ extern "C" int mi_scene_upload(mi_ctx* c, const mi_scene_desc* d) {
     for (const DMesh& M : live) if (M.material < 0 || M.tex[4] >= 0) c->mesh_maps = true;
     c->h_list = list; c->h_n_tri = n_list[0]; c->h_n_sphere = n_list[1]; c->h_n_unmasked = n_list[2] + n_list[3]; c->mask_valid = false;
     c->S.n_list_tri = n_list[0]; c->S.n_list_sphere = n_list[1]; c->S.n_list_plane = n_list[2]; c->S.n_list_volume = n_list[3];
+    c->S.n_list_lin = n_list_lin; c->S.top_meshf = top_meshf; c->list_tree = top_meshf >= 0;
     c->S.materials = (const DMaterial*)(b + off_mat);
     c->S.meshes = (const DMesh*)(b + off_mesh);
     c->S.meshf = (const DMeshF*)(b + off_meshf);
@@ -1405,6 +1468,7 @@ static int render_tiles(mi_ctx* c, const mi_camera_desc* cam, const mi_render_op
     if (!d_compact && writes_image) return fail(MI_ERR_INVALID, "output buffer is NULL");
     K1Args a;
     a.S = c->S;
+    if (o->flags & MI_OPT_NO_LIST_TREE) { a.S.top_meshf = -1; a.S.n_list_lin = a.S.n_list_tri; }      // every list Triangle one by one (cross-check)
     make_camera(cam, &a.C);
     for (int k = 0; k < 3; k++) { a.C.light[k] = c->point_light_pos[k]; a.C.ambient[k] = c->ambient[k]; }
     const bool phong = cam->shading_mode == MI_SHADE_PHONG;      // debug shader: own kernel, `variant` is ignored

@@ -156,6 +156,10 @@ struct DScene {
     const PT_CONST_AS float*     ftris;
     const PT_CONST_AS DMeshF*    meshf;
     int32_t n_list_tri, n_list_sphere, n_list_plane, n_list_volume;
+    // Top-level tree over the list's Triangles (long lists only): the first n_list_lin Triangles of `list` (the large
+    // ones) are tested one by one, the others sit in a padded SAH tree whose record is meshf[top_meshf] (the F-tree machinery of the
+    // two-stage mesh traversal, in world space); top_meshf = -1: no tree, n_list_lin = n_list_tri
+    int32_t n_list_lin, top_meshf;
     int32_t n_objects;
     int32_t n_meshes;
     int32_t n_nodes;

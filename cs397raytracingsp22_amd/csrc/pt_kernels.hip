@@ -731,6 +731,58 @@ __device__ __forceinline__ void test_object(const DScene& S, OP ob, int idx, f3 
     }
 }
 
+// ---- the padded-box machinery of the exact two-stage traversal (bvh_build.hpp states the bound): used by the
+//      mesh walkers wf_trav_f / wf_replay further down and by the top-level tree over the list's Triangles right below ----
+// bvh_build.hpp two_stage_pad, same f32 expression
+__device__ __forceinline__ bool two_stage_pad(const PT_CONST_AS DMeshF* F, f3 o, f3 d, float t_max, float& rho_out, float& dt_out) {
+    const float eps = 5.9604645e-08f;
+    const float dn = sqrtf((d.x * d.x + d.y * d.y) + d.z * d.z) * 1.000001f;
+    const float ox = o.x - F->cx, oy = o.y - F->cy, oz = o.z - F->cz;
+    const float Sr = (sqrtf((ox * ox + oy * oy) + oz * oz) + F->R) * 1.000001f;
+    const float E2 = F->E2, L = F->L;
+    const float B = 7.0f * eps * E2 * dn * 1.0e4f;
+    const float rho = 2.0f * eps * dn * E2 * (16.0f * Sr + 14.0f * L) * 1.0e4f + 11.0f * eps * L;
+    const float dt = 2.0f * (8.1f * eps * E2 * Sr * 1.0e4f + fabsf(t_max) * (B + 2.001f * eps));
+    rho_out = 4.0f * rho + 16.0f * eps * Sr;
+    dt_out = 2.0f * dt;
+    return (B <= 0.5f) && (Sr <= 1.0e12f) && (rho_out <= 1.0e30f) && (dt_out <= 1.0e30f);
+}
+
+// AABB test of pass 1: the box grown by rho, parameter range [t_lo, t_hi].  The padding is applied to the DIFFERENCES
+// (bmin - o) - rho and (bmax - o) + rho: a mesh far from its object-space origin has |o| >> rho, and o + rho would round
+// the padding away.
+__device__ __forceinline__ bool slab_padded(f3 bmin, f3 bmax, f3 o, float rho, f3 inv_d, float t_lo, float t_hi) {
+    float tmin = t_lo, tmax = t_hi;
+    {
+        float t0 = ((bmin.x - o.x) - rho) * inv_d.x, t1 = ((bmax.x - o.x) + rho) * inv_d.x;
+        bool sw = inv_d.x < 0.0f;
+        float ta = sw ? t1 : t0, tb = sw ? t0 : t1;
+        tmin = fmaxf(ta, tmin); tmax = fminf(tb, tmax);
+    }
+    {
+        float t0 = ((bmin.y - o.y) - rho) * inv_d.y, t1 = ((bmax.y - o.y) + rho) * inv_d.y;
+        bool sw = inv_d.y < 0.0f;
+        float ta = sw ? t1 : t0, tb = sw ? t0 : t1;
+        tmin = fmaxf(ta, tmin); tmax = fminf(tb, tmax);
+    }
+    {
+        float t0 = ((bmin.z - o.z) - rho) * inv_d.z, t1 = ((bmax.z - o.z) + rho) * inv_d.z;
+        bool sw = inv_d.z < 0.0f;
+        float ta = sw ? t1 : t0, tb = sw ? t0 : t1;
+        tmin = fmaxf(ta, tmin); tmax = fminf(tb, tmax);
+    }
+    return !(tmax <= tmin);
+}
+
+// A quantised F-node (bvh_build.hpp fq_encode): six 16-bit grid coordinates, decoded by one fmaf each — the operation the encoder
+// rounded outward against — and the link word.
+__device__ __forceinline__ void fq_box(float4 c, float4 g, f3& bmin, f3& bmax) {
+    const uint32_t w0 = __float_as_uint(c.x), w1 = __float_as_uint(c.y), w2 = __float_as_uint(c.z);
+    bmin = mk3(__builtin_fmaf((float)(w0 & 0xffffu), g.x, g.y), __builtin_fmaf((float)(w0 >> 16), g.x, g.z), __builtin_fmaf((float)(w1 & 0xffffu), g.x, g.w));
+    bmax = mk3(__builtin_fmaf((float)(w1 >> 16), g.x, g.y), __builtin_fmaf((float)(w2 & 0xffffu), g.x, g.z), __builtin_fmaf((float)(w2 >> 16), g.x, g.w));
+}
+
+
 // Scene::intersect_ray over the non-mesh objects (tracing.rs:330-344) through the
 // kind-grouped list: one tight loop per kind, the record of the next object loaded (scalar
 // load, wave-uniform address) while the current one is tested.
@@ -777,7 +829,13 @@ __device__ __forceinline__ void sphere_stage1(REC ob, f3 o, f3 d, float a, float
 }
 
 // RARE = false compiles the Plane / ConvexVolume loop out (a scene without either: the Cornell configurations)
-template <bool GV = true, bool RARE = true>
+// TOP = true (long lists; the scene compiler decides): only the first n_list_lin Triangles — the large ones — are tested one by one; the others
+// sit in a top-level tree (mi_rt.cpp, bvh_build.hpp FTree: SAH over the triangles' boxes, 16-byte quantised nodes) that every lane walks
+// with the boxes padded by the proven bound on what the reference's f32 test can accept, running the reference's own test on the triangles of
+// the leaves it reaches.  A triangle whose padded box the ray misses would have failed that test; the closest hit over the rest does not
+// depend on the order of evaluation (ties: the lower Scene.objects index, which the leaf triangles carry).  A ray the bound does not cover
+// (B > 1/2, anything non-finite) makes its whole wave test the rest of the list one by one.
+template <bool GV = true, bool RARE = true, bool TOP = false>
 __device__ __forceinline__ void intersect_list(const DScene& S, f3 o, f3 d, float t_min, float t_max, Rng& rng, Best& best) {
     auto L = S.list;
     int k = 0;
@@ -785,7 +843,7 @@ __device__ __forceinline__ void intersect_list(const DScene& S, f3 o, f3 d, floa
     {   // Triangle::intersect_ray geometry.rs:431-450.  Two triangles per trip: the two
         // Moller-Trumbore chains (cross, dot, correctly rounded 1/g, ...) are independent, so the
         // in-order issue overlaps their latencies; `consider` is applied in list order.
-        const int end = S.n_list_tri;
+        const int end = TOP ? S.n_list_lin : S.n_list_tri;
         for (; k + 1 < end; k += 2) {
             auto r0 = &L[k]; auto r1 = &L[k + 1];
             // both records' constants are asked for BEFORE the first test: its reciprocal's range check is a branch, and scalar loads
@@ -804,6 +862,73 @@ __device__ __forceinline__ void intersect_list(const DScene& S, f3 o, f3 d, floa
             bool ok0 = tri_t(o, d, ld3(r0->f), ld3(r0->f + 3), ld3(r0->f + 6), t_min, t_max, t0, u0, v0);
             consider_list(best, have, ok0, t0, r0->index, -1);
         }
+    }
+    if (TOP) {
+        auto F = &S.meshf[S.top_meshf];
+        float rho, dt;
+        const bool covered = two_stage_pad(F, o, d, t_max, rho, dt);
+        if (__builtin_amdgcn_ballot_w64(!covered) != 0ull) {
+            for (k = S.n_list_lin; k < S.n_list_tri; k++) {               // the plain loop for this wave
+                auto r0 = &L[k];
+                float t0, u0, v0;
+                bool ok0 = tri_t(o, d, ld3(r0->f), ld3(r0->f + 3), ld3(r0->f + 6), t_min, t_max, t0, u0, v0);
+                consider_list(best, have, ok0, t0, r0->index, -1);
+            }
+        } else {
+            cf4_ptr FN = (cf4_ptr)S.fnodes;
+            cf4_ptr FT = (cf4_ptr)S.ftris;
+            f3 inv;
+            rcp3_exact(d.x, d.y, d.z, inv.x, inv.y, inv.z);
+            const float t_lo = t_min - dt, t_hi = t_max + dt;
+            const float4 grid = make_float4(F->qs, F->qbx, F->qby, F->qbz);
+            const int fend = F->fnode_end, ftb = F->ftri_begin;
+            int fi = F->fnode_begin;
+            // pre-order with skip links, no stack (all hits are wanted); the wave votes between a burst of box steps and the triangle tests
+            // of the leaves reached, as the walkers do (a lane that has reached a leaf waits for the leaf step)
+            bool atleaf = false;
+            float4 c = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (fi < fend) c = FN[fi];
+            // The window's far end follows the closest hit so far: a triangle that can still win (strictly closer, or as close with a lower
+            // index) passes the reference's test at a computed t <= best.t, so the exact line meets its padded box before best.t + dt (the
+            // bound's dt covers computed-vs-exact); nothing beyond that can change the result.  NaN distances leave the window as it is.
+            float thi = have ? fminf(t_hi, best.t + dt) : t_hi;
+            while (__builtin_amdgcn_ballot_w64(fi < fend) != 0ull) {
+#pragma unroll
+                for (int j = 0; j < 6; j++) {
+                    const bool act = (fi < fend) & !atleaf;
+                    f3 bmin, bmax;
+                    fq_box(c, grid, bmin, bmax);
+                    const bool hit = slab_padded(bmin, bmax, o, rho, inv, t_lo, thi);
+                    const int link = __float_as_int(c.w);
+                    const bool leaf = link < 0;
+                    const bool stop = act & hit & leaf;
+                    const int nxt = (hit | leaf) ? fi + 1 : link;            // a leaf's successor is the next node either way
+                    atleaf = atleaf | stop;
+                    const bool move = act & !stop;
+                    fi = move ? nxt : fi;
+                    if (move & (fi < fend)) c = FN[fi];
+                }
+                const int n_leaf = __popcll(__builtin_amdgcn_ballot_w64(atleaf));
+                const int n_walk = __popcll(__builtin_amdgcn_ballot_w64((fi < fend) & !atleaf));
+                if (n_leaf * 3 >= n_walk) {
+                    if (atleaf) {
+                        const int payload = __float_as_int(c.w) & 0x7fffffff;
+                        const int first = ftb + (payload >> 3), count = (payload & 7) + 1;
+                        for (int j = 0; j < count; j++) {
+                            const float4 t0 = FT[3 * (first + j)], t1 = FT[3 * (first + j) + 1], t2 = FT[3 * (first + j) + 2];
+                            float t, u, v;
+                            const bool ok = tri_t(o, d, mk3(t0.x, t0.y, t0.z), mk3(t1.x, t1.y, t1.z), mk3(t2.x, t2.y, t2.z), t_min, t_max, t, u, v);
+                            consider_list(best, have, ok, t, __float_as_int(t0.w), -1);       // t0.w: the triangle's Scene.objects index
+                        }
+                        fi = fi + 1;
+                        atleaf = false;
+                        if (fi < fend) c = FN[fi];
+                        thi = have ? fminf(t_hi, best.t + dt) : t_hi;
+                    }
+                }
+            }
+        }
+        k = S.n_list_tri;
     }
     {   // Sphere::intersect_ray geometry.rs:395-413, staged (above)
         const int end = k + S.n_list_sphere;
@@ -1565,7 +1690,8 @@ __device__ __forceinline__ void wf_pixel_of(const WfArgs& A, uint32_t pix, uint3
 // MESH = false: the lean form for launches that cannot meet a mesh hit (iteration 0 and the class-A part of a later pass)
 // RARE = false: the scene holds no Plane and no ConvexVolume (their loop and the free-flight code are compiled out)
 // ITER0 = true: the camera-ray pass (Camera::generate_rays instead of a state load; always the lean form)
-template <bool LDS, bool SIG, bool GV, int MESH, bool RARE, bool ITER0>
+// TOP = true: the list's Triangles sit in a top-level tree (intersect_list<.., TOP>; scenes with long lists only)
+template <bool LDS, bool SIG, bool GV, int MESH, bool RARE, bool ITER0, bool TOP = false>
 __global__ __launch_bounds__(kBlock, (MESH == 2 ? PT_MAIN_WAVES : (MESH == 1 ? PT_MAIN_WAVES_NOTEX : PT_MAIN_WAVES_LEAN))) void wf_main(WfArgs A) {
     const DScene& S = A.S;
     const DCamera& C = A.C;
@@ -1737,7 +1863,7 @@ __global__ __launch_bounds__(kBlock, (MESH == 2 ? PT_MAIN_WAVES : (MESH == 1 ? P
             tm = 0; enters = false;
             best.obj = -1; best.t = 0.0f; best.tri = -1; best.u = best.v = 0.0f;
             if (first && ITER0 && A.tile_mask) intersect_list_masked<GV, RARE>(S, list_mask, P.o, P.d, t_min, t_max, P.rng, best);
-            else intersect_list<GV, RARE>(S, P.o, P.d, t_min, t_max, P.rng, best);
+            else intersect_list<GV, RARE, TOP>(S, P.o, P.d, t_min, t_max, P.rng, best);
             if (first) WF_STAMP(9);
             f3 oo, od, inv; int ti, tend, ttb;
             enters = enter_next_mesh(S, B, tm, P.o, P.d, t_min, t_max, oo, od, inv, ti, tend, ttb, first ? (uint32_t)mesh_word : 0xffffffffu);
@@ -2298,47 +2424,6 @@ __global__ __launch_bounds__(BS, 8) void wf_trav_i(WfArgs A) {
 // A ray the bound does not cover (B > 1/2, non-finite) or with more than kCandMax candidates in one mesh takes the plain
 // reference walk for that mesh inside wf_replay.
 
-// bvh_build.hpp two_stage_pad, same f32 expression
-__device__ __forceinline__ bool two_stage_pad(const PT_CONST_AS DMeshF* F, f3 o, f3 d, float t_max, float& rho_out, float& dt_out) {
-    const float eps = 5.9604645e-08f;
-    const float dn = sqrtf((d.x * d.x + d.y * d.y) + d.z * d.z) * 1.000001f;
-    const float ox = o.x - F->cx, oy = o.y - F->cy, oz = o.z - F->cz;
-    const float Sr = (sqrtf((ox * ox + oy * oy) + oz * oz) + F->R) * 1.000001f;
-    const float E2 = F->E2, L = F->L;
-    const float B = 7.0f * eps * E2 * dn * 1.0e4f;
-    const float rho = 2.0f * eps * dn * E2 * (16.0f * Sr + 14.0f * L) * 1.0e4f + 11.0f * eps * L;
-    const float dt = 2.0f * (8.1f * eps * E2 * Sr * 1.0e4f + fabsf(t_max) * (B + 2.001f * eps));
-    rho_out = 4.0f * rho + 16.0f * eps * Sr;
-    dt_out = 2.0f * dt;
-    return (B <= 0.5f) && (Sr <= 1.0e12f) && (rho_out <= 1.0e30f) && (dt_out <= 1.0e30f);
-}
-
-// AABB test of pass 1: the box grown by rho, parameter range [t_lo, t_hi].  The padding is applied to the DIFFERENCES
-// (bmin - o) - rho and (bmax - o) + rho: a mesh far from its object-space origin has |o| >> rho, and o + rho would round
-// the padding away.
-__device__ __forceinline__ bool slab_padded(f3 bmin, f3 bmax, f3 o, float rho, f3 inv_d, float t_lo, float t_hi) {
-    float tmin = t_lo, tmax = t_hi;
-    {
-        float t0 = ((bmin.x - o.x) - rho) * inv_d.x, t1 = ((bmax.x - o.x) + rho) * inv_d.x;
-        bool sw = inv_d.x < 0.0f;
-        float ta = sw ? t1 : t0, tb = sw ? t0 : t1;
-        tmin = fmaxf(ta, tmin); tmax = fminf(tb, tmax);
-    }
-    {
-        float t0 = ((bmin.y - o.y) - rho) * inv_d.y, t1 = ((bmax.y - o.y) + rho) * inv_d.y;
-        bool sw = inv_d.y < 0.0f;
-        float ta = sw ? t1 : t0, tb = sw ? t0 : t1;
-        tmin = fmaxf(ta, tmin); tmax = fminf(tb, tmax);
-    }
-    {
-        float t0 = ((bmin.z - o.z) - rho) * inv_d.z, t1 = ((bmax.z - o.z) + rho) * inv_d.z;
-        bool sw = inv_d.z < 0.0f;
-        float ta = sw ? t1 : t0, tb = sw ? t0 : t1;
-        tmin = fmaxf(ta, tmin); tmax = fminf(tb, tmax);
-    }
-    return !(tmax <= tmin);
-}
-
 // next two-stage mesh (index >= m, bit set in `mask`) whose REFERENCE root box the ray enters (geometry.rs:103 at the root:
 // nothing below can be reached otherwise); sets up the object-space ray and the padded walk.  `fallback` receives the bits
 // of entered meshes the bound does not cover for this ray.
@@ -2431,14 +2516,6 @@ __global__ __launch_bounds__(256) void wf_filter_f(WfArgs A) {
         if (n_now >= 1024u) flush();
     }
     flush();
-}
-
-// A quantised F-node (bvh_build.hpp fq_encode): six 16-bit grid coordinates, decoded by one fmaf each — the operation the encoder
-// rounded outward against — and the link word.
-__device__ __forceinline__ void fq_box(float4 c, float4 g, f3& bmin, f3& bmax) {
-    const uint32_t w0 = __float_as_uint(c.x), w1 = __float_as_uint(c.y), w2 = __float_as_uint(c.z);
-    bmin = mk3(__builtin_fmaf((float)(w0 & 0xffffu), g.x, g.y), __builtin_fmaf((float)(w0 >> 16), g.x, g.z), __builtin_fmaf((float)(w1 & 0xffffu), g.x, g.w));
-    bmax = mk3(__builtin_fmaf((float)(w1 >> 16), g.x, g.y), __builtin_fmaf((float)(w2 & 0xffffu), g.x, g.z), __builtin_fmaf((float)(w2 >> 16), g.x, g.w));
 }
 
 // pass 1: persistent walkers over the traversal queue (work distribution and refill exactly as wf_trav)
@@ -2914,7 +2991,9 @@ hipError_t launch_wf_main(const WfArgs& a, uint32_t n_blocks, bool sig, bool gv,
     // part of a later pass, every pass of a scene without meshes.
     const bool lean = a.iter0 != 0u || a.part == 1u || a.S.n_meshes == 0;
     const bool rare = a.S.n_list_plane + a.S.n_list_volume > 0;          // (gv implies rare: it is a kind of ConvexVolume)
-#define PT_WF_MAIN2(G, V, M, R, I) hipLaunchKernelGGL((wf_main<false, G, V, M, R, I>), grid, block, 0, stream, a)
+    const bool top = a.S.top_meshf >= 0;                                  // the list's Triangles in a top-level tree (long lists)
+#define PT_WF_MAIN2(G, V, M, R, I) do { if (top) hipLaunchKernelGGL((wf_main<false, G, V, M, R, I, true>), grid, block, 0, stream, a); \
+                                        else hipLaunchKernelGGL((wf_main<false, G, V, M, R, I, false>), grid, block, 0, stream, a); } while (0)
 #define PT_WF_SIG(V, M, R, I) do { if (sig) PT_WF_MAIN2(true, V, M, R, I); else PT_WF_MAIN2(false, V, M, R, I); } while (0)
 #define PT_WF_MESH(V, R) do { if (a.iter0) PT_WF_SIG(V, 0, R, true); else if (lean) PT_WF_SIG(V, 0, R, false); \
                               else if (tex) PT_WF_SIG(V, 2, R, false); else PT_WF_SIG(V, 1, R, false); } while (0)

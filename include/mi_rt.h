@@ -199,6 +199,8 @@ typedef struct mi_render_opts {
 #define MI_OPT_REFERENCE_WALK  2u   /* meshes: walk the reference's own BVH (geometry.rs:94-119) node by node even where the
                                      * exact two-stage traversal would be used: same image, slower on large meshes */
 #define MI_OPT_TWO_STAGE       4u   /* meshes: use the two-stage traversal for every mesh, whatever its size: same image */
+#define MI_OPT_NO_LIST_TREE    8u   /* long lists: test every Triangle of Scene.objects one by one instead of walking the top-level tree the scene
+                                     * compiler builds over them (>= 32 small triangles): same image */
 
 typedef enum mi_variant {
     MI_VARIANT_DEFAULT    = 0,  /* library picks (currently MI_VARIANT_WAVEFRONT)                  */

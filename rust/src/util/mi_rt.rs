@@ -38,7 +38,7 @@ use std::os::raw::{c_char, c_int, c_void};
 #[repr(C)] #[derive(Default)] pub struct mi_stats { pub samples: u64, pub pixels: u64, pub tiles: u32, pub tiles_padded: u32, pub kernel_ms: f32, pub total_ms: f32, pub scene_bytes: u32, pub scene_in_lds: u32 }
 pub enum mi_ctx {}
 pub enum mi_multi {}
-pub const MI_OPT_NO_TILE_MASKS: u32 = 1; pub const MI_OPT_REFERENCE_WALK: u32 = 2; pub const MI_OPT_TWO_STAGE: u32 = 4;
+pub const MI_OPT_NO_TILE_MASKS: u32 = 1; pub const MI_OPT_REFERENCE_WALK: u32 = 2; pub const MI_OPT_TWO_STAGE: u32 = 4; pub const MI_OPT_NO_LIST_TREE: u32 = 8;
 pub const MI_RT_ABI_VERSION: c_int = 5;
 // mi_material_kind / mi_object_kind / projection and shading modes (include/mi_rt.h)
 pub const MI_MAT_LAMBERTIAN: i32 = 0; pub const MI_MAT_METAL: i32 = 1; pub const MI_MAT_DIELECTRIC: i32 = 2;

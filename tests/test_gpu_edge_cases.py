@@ -270,3 +270,68 @@ def test_textures_of_odd_sizes(gpu_ctx, orc, variant):
         xf = cgmath.mul(cgmath.from_translation((0.0, 2.0, 0.0)), cgmath.from_scale(1.6))
         sc = Scene(camera(56, 44, 4, 4), scenes.cornell_walls() + [StaticMesh(mesh, None, maps, xf)])
         compare(gpu_ctx, orc, sc, variant=variant, seed=6)
+
+
+def _many_triangles(rng, n, lo=(-2.6, 0.2, -2.6), hi=(2.6, 5.6, 2.6), size=0.35):
+    objs = []
+    for k in range(n):
+        c = rng.uniform(lo, hi)
+        p = c + rng.uniform(-size, size, (3, 3))
+        mat = Lambertian(albedo=tuple(map(float, rng.uniform(0.2, 0.9, 3))), emission=(0.3, 0.3, 0.3) if k % 7 == 0 else (0, 0, 0)) if k % 3 else \
+            Metal(albedo=(0.8, 0.8, 0.8), emission=(0, 0, 0), roughness=float(rng.uniform(0, 0.5)))
+        objs.append(Triangle(tuple(map(float, p[0])), tuple(map(float, p[1])), tuple(map(float, p[2])), mat))
+    return objs
+
+
+@pytest.mark.parametrize("variant", [abi.MI_VARIANT_DEFAULT, abi.MI_VARIANT_VOTED])
+def test_long_triangle_lists_walk_a_top_level_tree(gpu_ctx, orc, variant):
+    """96 or more small Triangles in Scene.objects: the scene compiler puts them into a top-level tree (the walls — 32 x the median
+    |e1||e2| and more — stay in front and are tested one by one) and the wavefront pipeline's object list walks it with padded boxes,
+    running the reference's own test on the leaves it reaches.  Same paths as the oracle's linear loop, and as the library's own with
+    MI_OPT_NO_LIST_TREE; a glass sphere and a metal one keep the bounce directions off unit length."""
+    rng = np.random.default_rng(77)
+    objs = scenes.cornell_walls() + _many_triangles(rng, 150) + scenes.cornell_spheres()
+    # degenerate and awkward members of the tree: a zero-area triangle, a sliver, two identical triangles with different materials
+    objs.append(Triangle((0.5, 1.0, 0.5), (0.5, 1.0, 0.5), (0.7, 1.3, 0.5), Lambertian(albedo=(0.9, 0.9, 0.1))))
+    objs.append(Triangle((-1.0, 2.0, 0.0), (1.0, 2.0, 1e-6), (0.0, 2.0, 5e-7), Lambertian(albedo=(0.1, 0.9, 0.9))))
+    twin = ((-0.6, 3.0, 0.2), (0.1, 3.1, 0.3), (-0.2, 3.6, 0.1))
+    objs.append(Triangle(*twin, Lambertian(albedo=(0.9, 0.1, 0.1))))
+    objs.append(Triangle(*twin, Lambertian(albedo=(0.1, 0.9, 0.1), emission=(2.0, 2.0, 2.0))))     # never seen: the first entry wins the tie
+    objs = [objs[i] for i in rng.permutation(len(objs))]
+    sc = Scene(camera(110, 80, 4, 7), objs)
+    compare(gpu_ctx, orc, sc, variant=variant)
+    if variant == abi.MI_VARIANT_DEFAULT:
+        flat = sc.flatten()
+        gpu_ctx.upload(flat)
+        f0, _, s0, _ = gpu_ctx.render(sc.camera, seed=3, want_u8=False, want_sig=True)
+        f1, _, s1, _ = gpu_ctx.render(sc.camera, seed=3, want_u8=False, want_sig=True, flags=abi.MI_OPT_NO_LIST_TREE)
+        assert np.array_equal(s0, s1) and np.array_equal(f0, f1)
+        gpu_ctx.render(sc.camera, seed=3, want_u8=False)
+        with_tree = gpu_ctx.last_pipeline_ms()["wf_main_ms"]
+        gpu_ctx.render(sc.camera, seed=3, want_u8=False, flags=abi.MI_OPT_NO_LIST_TREE)
+        assert gpu_ctx.last_pipeline_counts()["segments"] > 0 and with_tree > 0
+
+
+def test_top_level_tree_rays_the_bound_does_not_cover(gpu_ctx, orc):
+    """The padding bound needs B = 7 eps E2 |d| / 1e-4 <= 1/2.  A hundred and twenty triangles of |e1||e2| ~ 50 (tree built: B = 0.21 |d|) under an
+    orthographic camera whose view_dir has length 3 (tracing.rs:200: the direction is not normalised) send every camera ray in
+    with B = 0.63: those waves test the list one by one; the bounce rays (in-ball directions) walk the tree.  Same paths as the oracle."""
+    rng = np.random.default_rng(5)
+    objs = []
+    for k in range(120):
+        c = rng.uniform((-12.0, -12.0, -30.0), (12.0, 12.0, -10.0))
+        p = c + rng.uniform(-5.0, 5.0, (3, 3))
+        objs.append(Triangle(tuple(map(float, p[0])), tuple(map(float, p[1])), tuple(map(float, p[2])),
+                             Lambertian(albedo=tuple(map(float, rng.uniform(0.3, 0.9, 3))), emission=(0.2, 0.2, 0.2))))
+    objs.append(Sphere((0.0, 0.0, -20.0), 3.0, Metal(albedo=(0.9, 0.9, 0.9), emission=(0, 0, 0), roughness=0.05)))
+    cam = camera(96, 72, 4, 5, projection_mode=abi.MI_PROJ_ORTHOGRAPHIC, eyepoint=(0.0, 0.0, 8.0), view_dir=(0.0, 0.0, -3.0), focal_length=0.05)
+    compare(gpu_ctx, orc, Scene(cam, objs))
+
+
+def test_long_lists_with_triangles_of_one_size_everywhere(gpu_ctx, orc):
+    """No outliers: every triangle goes into the tree (nothing stays in front), lists of exactly the minimum length, and a list one short
+    of it (no tree at all)."""
+    for n in (96, 95, 300):
+        rng = np.random.default_rng(100 + n)
+        objs = _many_triangles(rng, n, size=0.5) + [Sphere((0.0, 2.5, 0.0), 0.8, Dielectric(1.5))]
+        compare(gpu_ctx, orc, Scene(camera(80, 60, 4, 6), objs), seed=n)
