@@ -41,6 +41,7 @@ hipError_t launch_phong(const K1Args& a, uint32_t n_blocks, bool sig, hipStream_
 hipError_t launch_branch(const K1Args& a, uint32_t n_blocks, uint32_t path_samples, bool sig, hipStream_t stream);
 hipError_t launch_wf_trav(const WfArgs& a, uint32_t n_blocks, int lds_mode, size_t lds_bytes, bool* big_lds_enabled, hipStream_t stream);
 hipError_t launch_wf_trav_i(const WfArgs& a, uint32_t n_blocks, size_t lds_bytes, bool leaf_lds, bool* big_lds_enabled, hipStream_t stream);
+hipError_t launch_wf_trav_p(const WfArgs& a, uint32_t n_blocks, size_t lds_bytes, hipStream_t stream);
 hipError_t launch_wf_filter_f(const WfArgs& a, uint32_t blocks_per_shard, hipStream_t stream);
 hipError_t launch_wf_trav_f(const WfArgs& a, uint32_t n_blocks, hipStream_t stream);
 hipError_t launch_wf_replay(const WfArgs& a, uint32_t n_blocks, hipStream_t stream);
@@ -1213,26 +1214,29 @@ static int render_tiles_wavefront(mi_ctx* c, const K1Args& k, const mi_camera_de
     const size_t inode_bytes = (size_t)ref_inodes * 32;               // wf_trav_i: the interior nodes only
     const int ref_lnodes = ref_nodes - ref_inodes;                    // the split pools hold every tree in the node pool's order: leaves = nodes - interior nodes
     const size_t split_bytes = inode_bytes + (size_t)ref_lnodes * 48; // wf_trav_i<.., LEAF_LDS>: interior and leaf records
+    const size_t pair_bytes = (((size_t)ref_inodes * (size_t)kPairStride + 15) & ~(size_t)15) + (size_t)ref_lnodes * 48;   // wf_trav_i<.., PAIR>: 56-byte interior records
     // 3 = the image needs most of a CU's 160 KB: ONE 1024-thread block per CU (16 waves).  4 = wf_trav_i: interior nodes in LDS, leaves
     // from global memory — chosen over 3 whenever two of its blocks fit a CU (8 waves per SIMD instead of 4), and the only LDS mode
     // left for images beyond 156 KB whose interior nodes still fit
     int trav_lds_mode = 0;
     if (ref_nodes > 0 && !c->tune.global_bvh) {
-        if (split_bytes <= 64u * 1024u) trav_lds_mode = 5;          // (= node_bytes: both images hold every node once and every triangle once)
+        if (pair_bytes <= 40u * 1024u) trav_lds_mode = 6;           // four 512-thread blocks per CU = 8 waves per SIMD
+        else if (split_bytes <= 64u * 1024u) trav_lds_mode = 5;     // (= node_bytes: both images hold every node once and every triangle once)
         else if (node_bytes <= 64u * 1024u) trav_lds_mode = 2;
         else if (inode_bytes <= 78u * 1024u) trav_lds_mode = 4;
         else if (node_bytes <= 156u * 1024u) trav_lds_mode = 3;
         else if (inode_bytes <= 156u * 1024u) trav_lds_mode = 4;
     }
     // 5 = wf_trav_i with the leaf records in LDS too (the whole split image within 64 KB): the explicit links make its interior step shorter than wf_trav's
+    // 6 = the same with the interior records in the paired layout (near / far plane per axis behind one 8-byte read: no selects in the box test)
     if (c->tune.trav_lds >= 0) {
         const int m = c->tune.trav_lds;
         if (m == 0 || (m == 2 && node_bytes <= 64u * 1024u) || (m == 3 && node_bytes <= 156u * 1024u) || (m == 4 && inode_bytes <= 156u * 1024u && ref_nodes > 0) ||
-            (m == 5 && split_bytes <= 64u * 1024u && ref_nodes > 0)) trav_lds_mode = m;
+            (m == 5 && split_bytes <= 64u * 1024u && ref_nodes > 0) || (m == 6 && pair_bytes <= 40u * 1024u && ref_nodes > 0)) trav_lds_mode = m;
     }
-    const size_t trav_lds_bytes = trav_lds_mode == 5 ? split_bytes : (trav_lds_mode == 4 ? inode_bytes : (trav_lds_mode >= 2 ? node_bytes : 0));
+    const size_t trav_lds_bytes = trav_lds_mode == 6 ? pair_bytes : trav_lds_mode == 5 ? split_bytes : (trav_lds_mode == 4 ? inode_bytes : (trav_lds_mode >= 2 ? node_bytes : 0));
     a.R.lds_nodes = trav_lds_mode >= 4 ? (uint32_t)ref_inodes : (trav_lds_mode ? (uint32_t)ref_nodes : 0);
-    a.R.lds_tris = (trav_lds_mode == 2 || trav_lds_mode == 3) ? (uint32_t)ref_e2 : (trav_lds_mode == 5 ? (uint32_t)ref_lnodes : 0);   // e2 entries / leaf records staged behind the nodes
+    a.R.lds_tris = (trav_lds_mode == 2 || trav_lds_mode == 3) ? (uint32_t)ref_e2 : (trav_lds_mode >= 5 ? (uint32_t)ref_lnodes : 0);   // e2 entries / leaf records staged behind the nodes
     a.cand = (uint2*)c->d_cand; a.cand_hdr = (uint2*)c->d_cand_hdr;
     float4* bufs[2] = { (float4*)c->d_wf_a, (float4*)c->d_wf_b };
     uint32_t trav_bpc = 6;                  // resident blocks per CU: bounded by LDS (160 KB) and by 8 waves/SIMD
@@ -1240,6 +1244,7 @@ static int render_tiles_wavefront(mi_ctx* c, const K1Args& k, const mi_camera_de
     if (trav_lds_mode == 3) trav_bpc = 1;
     if (trav_lds_mode == 4) trav_bpc = inode_bytes <= 78u * 1024u ? 2 : 1;
     if (trav_lds_mode == 5) { trav_bpc = (uint32_t)((160u * 1024u) / (split_bytes ? split_bytes : 1)); if (trav_bpc > 8) trav_bpc = 8; if (trav_bpc < 2) trav_bpc = 2; }
+    if (trav_lds_mode == 6) { trav_bpc = (uint32_t)((160u * 1024u) / (pair_bytes ? pair_bytes : 1)); if (trav_bpc > 4) trav_bpc = 4; if (trav_bpc < 1) trav_bpc = 1; }
     if (c->tune.trav_bpc > 0) trav_bpc = (uint32_t)c->tune.trav_bpc;
     const uint32_t trav_blocks = (uint32_t)c->n_cus * trav_bpc;
     const uint32_t travf_blocks = (uint32_t)c->n_cus * (c->tune.travf_bpc > 0 ? (uint32_t)c->tune.travf_bpc : 6u), replay_blocks = (uint32_t)c->n_cus * 8u;
@@ -1406,7 +1411,8 @@ static int render_tiles_wavefront(mi_ctx* c, const K1Args& k, const mi_camera_de
             if (ref_walk) {
                 a.trav_mask = ref_mask;
                 const uint32_t blocks = side_by_side ? (uint32_t)c->n_cus * conc_trav_bpc : trav_blocks;
-                if (trav_lds_mode >= 4) WF_TIMED(1, launch_wf_trav_i(a, blocks, trav_lds_bytes, trav_lds_mode == 5, &c->big_lds_enabled_i, stream));
+                if (trav_lds_mode == 6) WF_TIMED(1, launch_wf_trav_p(a, blocks, trav_lds_bytes, stream));
+                else if (trav_lds_mode >= 4) WF_TIMED(1, launch_wf_trav_i(a, blocks, trav_lds_bytes, trav_lds_mode == 5, &c->big_lds_enabled_i, stream));
                 else WF_TIMED(1, launch_wf_trav(a, blocks, trav_lds_mode, trav_lds_bytes, &c->big_lds_enabled, stream));
             }
             if (ts_mask) {

@@ -232,6 +232,7 @@ constexpr int kWfShards = 256;
 constexpr int kCandMax = 8;          // two-stage: candidate slots per queued ray (more passing triangles -> reference walk for that mesh)
 constexpr int kTwoStageMaxMeshes = 24;   // mesh index bits in cand_hdr
 constexpr int32_t kIdEnd = (int32_t)0x80000000;   // split pools: "no further node"
+constexpr int kPairStride = 56;                    // wf_trav_i<.., PAIR>: bytes of an interior record in the paired LDS layout (pt_kernels.hip)
 struct WfArgs {
     DScene  S;
     DCamera C;

@@ -104,6 +104,9 @@
 #ifndef PT_SPHERE_STAGED
 #define PT_SPHERE_STAGED 1  // list Spheres in two stages (sphere_stage1 / sphere_finish); 0 = one full test per sphere, for A/B
 #endif
+#ifndef PT_RNG_PEEP
+#define PT_RNG_PEEP 1       // value1_2 as one funnel shift, genm11 as one fma (both exact; the rejection sampler's loop 44 -> 38 VALU); 0 for A/B: cfg2 75.3 -> 74.9 ms
+#endif
 #ifndef PT_SEG_COUNT
 #define PT_SEG_COUNT 1      // wf_main counts its path segments (mi_last_pipeline_counts[6]); 0 only to measure what the count costs
 #endif
@@ -215,11 +218,21 @@ __device__ __forceinline__ uint32_t next_u32(Rng& r) {
     r.s1 = rotl32(s1, 13);
     return result;
 }
+#if PT_RNG_PEEP
+// 0x3f800000 | (bits >> 9) as ONE funnel shift: the low nine bits of the high word 0x7f become the sign and exponent
+__device__ __forceinline__ float value1_2(uint32_t bits) { return __uint_as_float(__builtin_amdgcn_alignbit(0x7fu, bits, 9u)); }
+#else
 __device__ __forceinline__ float value1_2(uint32_t bits) { return __uint_as_float(0x3f800000u | (bits >> 9)); }
+#endif
 // rand 0.8.4 gen_range(0.0..1.0): value1_2*1 + (0-1)      (exact)
 __device__ __forceinline__ float gen01(Rng& r) { return value1_2(next_u32(r)) * 1.0f + (0.0f - 1.0f); }
 // rand 0.8.4 gen_range(-1.0..1.0): value1_2*2 + (-1-2)    (exact)
+#if PT_RNG_PEEP
+// v in [1, 2): v * 2 is exact, so the reference's two roundings are one, and fma(v, 2, -3) is that one
+__device__ __forceinline__ float genm11(Rng& r) { return __builtin_fmaf(value1_2(next_u32(r)), 2.0f, -1.0f - 2.0f); }
+#else
 __device__ __forceinline__ float genm11(Rng& r) { return value1_2(next_u32(r)) * 2.0f + (-1.0f - 2.0f); }
+#endif
 // rand 0.8.4 gen_range(0..n): widening multiply + rejection zone
 __device__ __forceinline__ uint32_t gen_u32_below(Rng& r, uint32_t range, uint32_t zone) {
     for (;;) {
@@ -397,6 +410,16 @@ __device__ __forceinline__ bool slab(f3 bmin, f3 bmax, f3 o, f3 inv_d, float t_m
         float ta = sw ? t1 : t0, tb = sw ? t0 : t1;
         tmin = fmaxf(ta, tmin); tmax = fminf(tb, tmax);
     }
+    return !(tmax <= tmin);
+}
+
+// The same test on a box delivered as {near plane, far plane} per axis — near = (1/d < 0 ? bmax : bmin), which is what the swap of
+// geometry.rs:60-62 makes of t0 / t1: (near - o) * inv_d and (far - o) * inv_d are the reference's two products, already in order.
+__device__ __forceinline__ bool slab_nf(float2 x, float2 y, float2 z, f3 o, f3 inv_d, float t_min, float t_max) {
+    float tmin = t_min, tmax = t_max;
+    { const float ta = (x.x - o.x) * inv_d.x, tb = (x.y - o.x) * inv_d.x; tmin = fmaxf(ta, tmin); tmax = fminf(tb, tmax); }
+    { const float ta = (y.x - o.y) * inv_d.y, tb = (y.y - o.y) * inv_d.y; tmin = fmaxf(ta, tmin); tmax = fminf(tb, tmax); }
+    { const float ta = (z.x - o.z) * inv_d.z, tb = (z.y - o.z) * inv_d.z; tmin = fmaxf(ta, tmin); tmax = fminf(tb, tmax); }
     return !(tmax <= tmin);
 }
 
@@ -835,6 +858,11 @@ __device__ __forceinline__ void sphere_stage1(REC ob, f3 o, f3 d, float a, float
 // the leaves it reaches.  A triangle whose padded box the ray misses would have failed that test; the closest hit over the rest does not
 // depend on the order of evaluation (ties: the lower Scene.objects index, which the leaf triangles carry).  A ray the bound does not cover
 // (B > 1/2, anything non-finite) makes its whole wave test the rest of the list one by one.
+// (Round 4, measured negative: the Triangle / Sphere records of short lists staged in LDS by wf_main and read from there — a broadcast read
+// lands in VGPRs, and on gfx950 a v_mul_f32 with an SGPR operand issues at 0.6 of the rate of the same multiply on VGPRs
+// (tools/microbench/valu_rates.hip; 21 of a Triangle test's 57 instructions read the record).  cfg2 wf_main 50.1 -> 51.0 ms, the walkers
+// beside it 22.5 -> 23.3 ms: ten LDS reads and their waits per pair of triangles cost more than the faster multiplies give back.  Also without
+// effect: settling ties inside the Triangle loop without the index comparison (ascending order, `best` empty on entry) — 73.5 vs 73.4 ms.)
 template <bool GV = true, bool RARE = true, bool TOP = false>
 __device__ __forceinline__ void intersect_list(const DScene& S, f3 o, f3 d, float t_min, float t_max, Rng& rng, Best& best) {
     auto L = S.list;
@@ -844,6 +872,9 @@ __device__ __forceinline__ void intersect_list(const DScene& S, f3 o, f3 d, floa
         // Moller-Trumbore chains (cross, dot, correctly rounded 1/g, ...) are independent, so the
         // in-order issue overlaps their latencies; `consider` is applied in list order.
         const int end = TOP ? S.n_list_lin : S.n_list_tri;
+        // (Round 4, measured negative: the NEXT pair's records asked for before the current pair is tested, so that the scalar loads' latency
+        // passes behind the tests — 20 more live SGPRs, which the allocator pays for with v_writelane / v_readlane spills around the loop: cfg2
+        // 75.3 -> 76.7 ms.  Eight resident waves hide that latency already.)
         for (; k + 1 < end; k += 2) {
             auto r0 = &L[k]; auto r1 = &L[k + 1];
             // both records' constants are asked for BEFORE the first test: its reciprocal's range check is a branch, and scalar loads
@@ -1880,6 +1911,12 @@ __global__ __launch_bounds__(kBlock, (MESH == 2 ? PT_MAIN_WAVES : (MESH == 1 ? P
         }
         first = false;
         const bool cont = alive && !enters;             // its hit is known: nothing left to wait for
+        // (Round 4, measured negative: the BLOCK votes instead of the wave, and the continuing paths of its four waves are packed through LDS
+        // into full waves — whole waves' worth go round again 64 lanes wide, everything else is appended on the spot.  Bit-identical, and
+        // slower: cfg2 wf_main 49.8 -> 54.8 ms with one extra trip, 56.5 / 59.2 / 62.3 ms with two / three / five; the barriers tie four waves
+        // to the slowest one, waves left without a path keep their slots until the block ends, and the appends sit inside the loop.  Sweep of
+        // the wave's own threshold on the same day: no further trip at all 84.0 ms, 48 / 40 / 32 / 24 lanes 76.1 / 75.1 / 74.6 / 75.0 ms.
+        // tools/experiments/r04_block_repack.diff.)
         if (fuse_left == 0u || (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(cont)) < A.fuse_min) break;
         fuse_left--;
         pending = cont;
@@ -2218,8 +2255,16 @@ __global__ __launch_bounds__(BS, (BS == 256 ? PT_TRAV_WAVES : 4)) void wf_trav(W
 // LEAF_LDS = true (round 4): the leaf records staged in LDS as well, behind the interior ones — for trees whose WHOLE split image fits 64 KB
 // (the teapot: 7.6 + 11.5 KB, eight 256-thread blocks per CU as wf_trav<2, 256>).  Same storage cost as wf_trav's image, but the explicit
 // links make an interior step four VALU instructions shorter (no `ti < tend`, no `ti + 1`, no clamp of the prefetch behind the last node).
-template <int BS, bool MULTI, bool LEAF_LDS = false>
+// PAIR = true (round 4; needs LEAF_LDS): the interior records are re-laid while they are staged, 56 bytes each —
+//   {bmin.x, bmax.x, bmax.x, bmin.x}{.y ...}{.z ...}{link on a miss, link on a hit}, links to interior records as LDS byte offsets —
+// so that ONE 8-byte read at `record + (1/d < 0 ? 8 : 0)` per axis delivers {near plane, far plane} already in the order geometry.rs:60-62's
+// swap produces: the six v_cndmask per box test (sw ? t1 : t0) disappear.  Same subtractions and products on the same operands; what changes
+// is which register they arrive in.  On gfx950 a v_cndmask / v_min / v_max / shift issues in 4 cycles, an f32 add / mul or an integer add in 2
+// (tools/microbench/valu_rates.hip), so the step's issue time goes from 12 x 2 + 15 x 4 to 15 x 2 + 7 x 4 cycles.  The 56-byte stride
+// (14 words: gcd with 64 banks = 2) spreads the 8-byte reads of 32 lanes over all bank pairs.
+template <int BS, bool MULTI, bool LEAF_LDS = false, bool PAIR = false>
 __global__ __launch_bounds__(BS, 8) void wf_trav_i(WfArgs A) {
+    static_assert(!PAIR || LEAF_LDS, "the paired layout keeps the leaf records in LDS");
     const DScene& S = A.S;
     const uint32_t blocks_a = A.in_blkpfx[kWfShards];
     const uint32_t n_q = (A.in_blkpfx[2 * kWfShards] - blocks_a) * (uint32_t)kBlock;      // slots of the class-B blocks (wf_slot)
@@ -2228,21 +2273,44 @@ __global__ __launch_bounds__(BS, 8) void wf_trav_i(WfArgs A) {
     if (n_q < n_waves * 256u) chunk = max(64u, ((n_q + n_waves - 1u) / n_waves + 63u) & ~63u);
     const bool shared_part = n_waves * chunk < n_q;
     if (blockIdx.x * ((uint32_t)BS / 64u) * chunk >= n_q) return;
+    // PAIR: byte offset of the leaf records behind the 56-byte interior records (16-byte aligned)
+    const int pair_leaf_base = (((int)A.R.lds_nodes * kPairStride + 15) & ~15);
     {
         cf4_ptr gi = (cf4_ptr)S.inodes;
         const int nn = (int)A.R.lds_nodes * 2;
-        for (int k = threadIdx.x; k < nn; k += BS) k1_lds[k] = gi[k];
+        if (!PAIR) for (int k = threadIdx.x; k < nn; k += BS) k1_lds[k] = gi[k];
+        else {
+            float* w = (float*)k1_lds;
+            auto link = [](float f) { const int l = __float_as_int(f); return __int_as_float(l >= 0 ? l * kPairStride : l); };
+            for (int k = threadIdx.x; k < (int)A.R.lds_nodes; k += BS) {
+                const float4 a = gi[2 * k], b = gi[2 * k + 1];
+                float* r = w + k * (kPairStride / 4);
+                r[0] = a.x; r[1] = b.x; r[2] = b.x; r[3] = a.x;
+                r[4] = a.y; r[5] = b.y; r[6] = b.y; r[7] = a.y;
+                r[8] = a.z; r[9] = b.z; r[10] = b.z; r[11] = a.z;
+                r[12] = link(a.w); r[13] = link(b.w);
+            }
+        }
         if (LEAF_LDS) {
             cf4_ptr gl = (cf4_ptr)S.lnodes;
             const int nl = (int)A.R.lds_tris * 3;                    // float4 slots of the staged leaf records
-            for (int k = threadIdx.x; k < nl; k += BS) k1_lds[nn + k] = gl[k];
+            if (!PAIR) for (int k = threadIdx.x; k < nl; k += BS) k1_lds[nn + k] = gl[k];
+            else {
+                float4* ll = (float4*)((char*)k1_lds + pair_leaf_base);
+                for (int k = threadIdx.x; k < nl; k += BS) {
+                    float4 v = gl[k];
+                    if (k % 3 == 0) { const int l = __float_as_int(v.w); v.w = __int_as_float(l >= 0 ? l * kPairStride : l); }   // the link to the next node
+                    ll[k] = v;
+                }
+            }
         }
         // (Tried and dropped: links turned into LDS byte offsets while staging, so that a node fetch needs no address arithmetic — the shift
         // was folded into the address add already: walker 23.8 -> 23.8 ms on cfg2, 190.0 -> 190.9 ms on cfg4 with its leaves' links scaled on the fly.)
         __syncthreads();
     }
     const float4* IN = k1_lds;
-    const float4* LL = k1_lds + (int)A.R.lds_nodes * 2;              // LEAF_LDS: the leaf records
+    const float4* LL = PAIR ? (const float4*)((const char*)k1_lds + pair_leaf_base) : k1_lds + (int)A.R.lds_nodes * 2;   // LEAF_LDS: the leaf records
+    const char* PB = (const char*)k1_lds;                            // PAIR: interior records by byte offset
     // (Round 4, measured negative: the LDS image in two planes — all first halves, then all second halves, so that a 16-byte read of
     // node i starts at bank 4 i mod 64 and reaches all sixteen bank quads where the 32-byte stride reaches eight.  PMC, same box:
     // SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE 0.50 -> 0.39 here and 0.52 -> 0.41 in wf_trav, LDS-busy cycles -19 %, but the second plane's
@@ -2270,6 +2338,14 @@ __global__ __launch_bounds__(BS, 8) void wf_trav_i(WfArgs A) {
     int tm = 0, id = kIdEnd, tbtri = -1;                             // id: the node the lane stands on (>= 0 interior: c0, c1 hold it)
     float tbt = 0.0f, tbu = 0.0f, tbv = 0.0f;
     float4 c0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), c1 = c0;
+    // PAIR: the record the lane stands on as {near, far} per axis and its two links; sx / sy / sz = the axis' byte offset inside a record, + 8 where 1/d < 0
+    float2 px = make_float2(0.0f, 0.0f), py = px, pz = px; int2 plk = make_int2(0, 0);
+    int sx = 0, sy = 16, sz = 32;
+    auto pair_load = [&]() {
+        px = *(const float2*)(PB + (id + sx)); py = *(const float2*)(PB + (id + sy)); pz = *(const float2*)(PB + (id + sz));
+        plk = *(const int2*)(PB + (id + 48));
+    };
+    auto pair_signs = [&]() { sx = tinv.x < 0.0f ? 8 : 0; sy = tinv.y < 0.0f ? 24 : 16; sz = tinv.z < 0.0f ? 40 : 32; };   // geometry.rs:60 `if inv_d < 0.0`
 
     // Single-mesh form: mesh 0's record — inverse transform, root box, first node, object index — is read ONCE, here, instead of by
     // four dependent scalar loads in every refill (same values, same operations on them afterwards)
@@ -2280,15 +2356,16 @@ __global__ __launch_bounds__(BS, 8) void wf_trav_i(WfArgs A) {
         for (int k = 0; k < 16; k++) m0[k] = M->inv_transform[k];
         B.node(M->node_begin, r0, r1);
         root0 = M->i_root; obj0 = M->object_index; tb0 = M->tri_begin;
-        if (root0 >= 0) root0 = __float_as_int(IN1(root0).w);                 // the node a ray stands on after a passed root test
+        if (root0 >= 0) root0 = PAIR ? *(const int*)(PB + (root0 * kPairStride + 52)) : __float_as_int(IN1(root0).w);   // the node a ray stands on after a passed root test
     }
     // the ray has passed (or skipped, for a root that is a leaf) mesh tm's root test: stand on the first node to visit
     auto start_mesh = [&]() {
-        if (!MULTI) { id = root0; if (id >= 0) { c0 = IN0(id); c1 = IN1(id); } tbt = t_max; tbtri = -1; tbu = tbv = 0.0f; return; }
+        if (PAIR) pair_signs();
+        if (!MULTI) { id = root0; if (id >= 0) { if (PAIR) pair_load(); else { c0 = IN0(id); c1 = IN1(id); } } tbt = t_max; tbtri = -1; tbu = tbv = 0.0f; return; }
         const int root = S.meshes[tm].i_root;
         id = root;
-        if (root >= 0) { id = __float_as_int(IN1(root).w); }                  // root box passed with bound t_max: its left child
-        if (id >= 0) { c0 = IN0(id); c1 = IN1(id); }
+        if (root >= 0) { id = PAIR ? *(const int*)(PB + (root * kPairStride + 52)) : __float_as_int(IN1(root).w); }   // root box passed with bound t_max: its left child
+        if (id >= 0) { if (PAIR) pair_load(); else { c0 = IN0(id); c1 = IN1(id); } }
         tbt = t_max; tbtri = -1; tbu = tbv = 0.0f;
     };
 
@@ -2349,6 +2426,19 @@ __global__ __launch_bounds__(BS, 8) void wf_trav_i(WfArgs A) {
         const int n_leaf = __popcll(__builtin_amdgcn_ballot_w64(at_leaf));
         const int n_inner = __popcll(__builtin_amdgcn_ballot_w64(at_inner));
         if (n_inner >= n_leaf * PT_TRAVI_LEAF_W) {
+            if (PAIR) {
+                // lanes leave the burst when they reach a leaf or the end and stay out: the steps nest, no per-step select of `id`
+                bool on = have & (id >= 0);
+#pragma unroll
+                for (int j = 0; j < PT_TRAVL_BURST; j++) {
+                    if (on) {
+                        const bool hit = slab_nf(px, py, pz, too, tinv, t_min, tbt);                               // geometry.rs:103
+                        id = hit ? plk.y : plk.x;
+                        on = id >= 0;
+                        if (on) pair_load();
+                    }
+                }
+            } else
 #pragma unroll
             for (int j = 0; j < (LEAF_LDS ? PT_TRAVL_BURST : PT_TRAVI_BURST); j++) {
                 const bool act = have & (id >= 0);
@@ -2371,7 +2461,7 @@ __global__ __launch_bounds__(BS, 8) void wf_trav_i(WfArgs A) {
                     const int ltri = __float_as_int(l1.w);
                     tbt = ok ? t : tbt; tbtri = ok ? ltri : tbtri; tbu = ok ? u : tbu; tbv = ok ? v : tbv;
                     id = __float_as_int(l0.w);
-                    if (id >= 0) { c0 = IN0(id); c1 = IN1(id); }
+                    if (id >= 0) { if (PAIR) pair_load(); else { c0 = IN0(id); c1 = IN1(id); } }
                 }
             }
         }
@@ -3022,6 +3112,11 @@ hipError_t launch_wf_trav(const WfArgs& a, uint32_t n_blocks, int lds_mode, size
     }
     else if (lds_mode == 2) { if (multi) hipLaunchKernelGGL((wf_trav<2, 256, true>), grid, block, lds_bytes, stream, a); else hipLaunchKernelGGL((wf_trav<2, 256, false>), grid, block, lds_bytes, stream, a); }
     else { if (multi) hipLaunchKernelGGL((wf_trav<0, 256, true>), grid, block, 0, stream, a); else hipLaunchKernelGGL((wf_trav<0, 256, false>), grid, block, 0, stream, a); }
+    return hipGetLastError();
+}
+hipError_t launch_wf_trav_p(const WfArgs& a, uint32_t n_blocks, size_t lds_bytes, hipStream_t stream) {      // the paired layout: 512-thread blocks
+    if (a.trav_mask != 1u || a.S.n_meshes > 32) hipLaunchKernelGGL((wf_trav_i<512, true, true, true>), dim3(n_blocks), dim3(512), lds_bytes, stream, a);
+    else hipLaunchKernelGGL((wf_trav_i<512, false, true, true>), dim3(n_blocks), dim3(512), lds_bytes, stream, a);
     return hipGetLastError();
 }
 hipError_t launch_wf_trav_i(const WfArgs& a, uint32_t n_blocks, size_t lds_bytes, bool leaf_lds, bool* big_lds_enabled, hipStream_t stream) {

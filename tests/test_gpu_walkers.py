@@ -1,7 +1,7 @@
 """Every storage mode of the reference-tree walker gives the same paths: BVH in global memory (0), whole image in LDS with 256-thread
 blocks (2) or one 1024-thread block per CU (3), and wf_trav_i — interior nodes in LDS, leaves from global memory, two 1024-thread
-blocks per CU (4: what trees of 64 .. 150 KB such as obj/drone.obj take by default), or with the leaf records in LDS too (5: trees whose whole
-split image fits 64 KB).  The mode is a developer knob read once in
+blocks per CU (4: what trees of 64 .. 150 KB such as obj/drone.obj take by default), with the leaf records in LDS too (5: trees whose whole
+split image fits 64 KB), or that with the interior records in the paired {near, far} layout (6: the default for trees up to 40 KB, the teapot).  The mode is a developer knob read once in
 mi_ctx_create (MI_RT_WF_TRAV_LDS), so each mode gets a context of its own; signatures must equal the oracle's bit for bit."""
 import os
 
@@ -42,7 +42,7 @@ def test_walker_storage_modes_agree_with_the_oracle_teapot(orc):
     flat = sc.flatten()
     _, _, rsig, _ = orc.OracleScene(flat).render(sc.camera, seed=4)
     ref = None
-    for mode in (0, 2, 3, 4, 5):
+    for mode in (0, 2, 3, 4, 5, 6):
         f32, sig = render_with_mode(mode, flat, sc.camera, 4)
         assert int((sig != rsig).sum()) == 0, f"walker mode {mode}: paths differ from the oracle"
         ref = f32 if ref is None else ref
@@ -60,7 +60,7 @@ def test_walker_storage_modes_agree_several_meshes_and_a_leaf_root(orc):
     sc.objects.append(sc.objects[-3])                                     # the teapot once more (shared StaticMesh)
     flat = sc.flatten()
     _, _, rsig, _ = orc.OracleScene(flat).render(sc.camera, seed=11)
-    for mode in (2, 4, 5):
+    for mode in (2, 4, 5, 6):
         _, sig = render_with_mode(mode, flat, sc.camera, 11)
         assert int((sig != rsig).sum()) == 0, f"walker mode {mode}: paths differ from the oracle"
 
@@ -95,7 +95,7 @@ def test_pass_schedules_agree_with_the_oracle(orc, scene):
         assert np.array_equal(f32, ref), env
 
 
-@pytest.mark.parametrize("mode", [0, 2, 3, 4, 5])
+@pytest.mark.parametrize("mode", [0, 2, 3, 4, 5, 6])
 def test_axis_aligned_rays_through_meshes(orc, mode):
     """Rays with exactly zero direction components: 1/d is infinite on two axes and the slab test meets NaN products (0 * inf) at
     box planes through the ray, which the reference's f32::max / min drop (geometry.rs:59-76).  An orthographic camera along -z
