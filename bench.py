@@ -204,6 +204,7 @@ def report(args, sc, flat, world, backend, route, dt, kernel_ms, pipe, counts, e
     valu_issue = valu_lane = None
     if pmc is not None:
         valu = {k: {"ms": v["ms"], "valu_insts": v["valu_insts"], "issue_frac": v["valu_issue_frac"], "active_lanes": v["active_lanes"],
+                    "cycles_per_inst": v.get("valu_cycles_per_inst"), "issue_frac_of_measured_peak": v.get("valu_issue_frac_of_measured_peak"),
                     "lane_frac": (v["valu_issue_frac"] * v["active_lanes"] / 64.0 if v.get("valu_issue_frac") and v.get("active_lanes") else None),
                     "hbm_GBps": v["hbm_GBps"], "hbm_frac": (v["hbm_GBps"] / HBM_PEAK_GBS if v.get("hbm_GBps") else None)}
                 for k, v in pmc.get("per_kernel", {}).items() if v.get("valu_insts") or v.get("hbm_bytes")}
@@ -233,11 +234,12 @@ def report(args, sc, flat, world, backend, route, dt, kernel_ms, pipe, counts, e
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": frac,
                      "frac_x2_corrected": (frac if pmc is not None else None), "frac_raw_counters": frac_raw,
                      "valu_issue_frac": valu_issue, "valu_lane_frac": valu_lane, "valu_kernel": dom,
-                     "binding": "neither roof: the walkers are bound by instruction issue on partly filled waves (0.73-0.75 of the VALU rate at 36-37 "
-                                "of 64 lanes; their time follows the instruction count one to one: DESIGN.md section 4 K2); wf_main is one third "
-                                "instruction issue (+28 % VALU per segment = +10 % time, ablation) and two thirds the latency of dependent memory "
-                                "operations - state stream, per-lane gathers, appends - that 6-8 waves per SIMD cannot cover; HBM carries the path "
-                                "state at 0.21-0.28 of its peak",
+                     "binding": "VALU instruction issue on partly filled waves. Measured ceiling on gfx950 (tools/microbench/valu_rates.hip): one wave64 "
+                                "VALU instruction per ~2.5 cycles per SIMD; the walkers run at 2.4-2.6 cycles per instruction and wf_main's class-A form at "
+                                "2.7 (valu.*.cycles_per_inst, from SQ_INSTS_VALU and GRBM_GUI_ACTIVE of the committed PMC) with 37-52 of 64 lanes live, so "
+                                "kernel time follows the instruction count (walkers: -4.6 % instructions = -4.4 % time, paired-layout A/B); wf_main's "
+                                "class-B form adds the latency of its per-lane gathers (3.4 cycles per instruction); HBM carries the path state at "
+                                "0.21-0.28 of its peak. valu_issue_frac keeps the nominal 2 cycles / 2.4 GHz of earlier rounds for comparison",
                      "traffic": traffic, "traffic_source": traffic_source,
                      "traffic_model_bytes": model_bytes, "path_counts": counts,
                      "kernel_ms": kernel_ms,

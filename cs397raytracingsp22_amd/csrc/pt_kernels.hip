@@ -2438,14 +2438,16 @@ __global__ __launch_bounds__(BS, 8) void wf_trav_i(WfArgs A) {
                         if (on) pair_load();
                     }
                 }
-            } else
+            } else {
+                // (the nested form of the paired layout's burst, tried on the 32-byte records too: cfg4 walker 186.1 -> 186.7 ms, HEAD unchanged)
 #pragma unroll
-            for (int j = 0; j < (LEAF_LDS ? PT_TRAVL_BURST : PT_TRAVI_BURST); j++) {
-                const bool act = have & (id >= 0);
-                const bool hit = slab(mk3(c0.x, c0.y, c0.z), mk3(c1.x, c1.y, c1.z), too, tinv, t_min, tbt);      // geometry.rs:103
-                const int nxt = hit ? __float_as_int(c1.w) : __float_as_int(c0.w);
-                id = act ? nxt : id;
-                if (act & (id >= 0)) { c0 = IN0(id); c1 = IN1(id); }
+                for (int j = 0; j < (LEAF_LDS ? PT_TRAVL_BURST : PT_TRAVI_BURST); j++) {
+                    const bool act = have & (id >= 0);
+                    const bool hit = slab(mk3(c0.x, c0.y, c0.z), mk3(c1.x, c1.y, c1.z), too, tinv, t_min, tbt);      // geometry.rs:103
+                    const int nxt = hit ? __float_as_int(c1.w) : __float_as_int(c0.w);
+                    id = act ? nxt : id;
+                    if (act & (id >= 0)) { c0 = IN0(id); c1 = IN1(id); }
+                }
             }
         } else {
             for (int k = 0; k < ((LEAF_LDS ? PT_TRAVL_LEAF2 : PT_TRAVI_LEAF2) > 0 ? 2 : 1); k++) {

@@ -94,6 +94,12 @@ def main():
             tot_w += wb
         if "SQ_INSTS_VALU" in c:
             rec["valu_issue_frac"] = c["SQ_INSTS_VALU"] * VALU_CYCLES / (SIMDS * CLOCK_GHZ * 1e9 * rec["ms"] * 1e-3) if rec["ms"] else None
+            if c.get("GRBM_GUI_ACTIVE"):
+                # Measured ceiling (tools/microbench/valu_rates.hip, same counters): a SIMD issues one wave64 VALU instruction per ~2.5 cycles of
+                # the clock GRBM_GUI_ACTIVE counts (summed over the 8 XCDs), for 2-pass instructions and for 2- and 4-pass ones alternating;
+                # streams of 4-pass instructions only (min / max / cndmask / compares / shifts / anything with an SGPR operand) take 4.25, rcp / sqrt 8.25
+                rec["valu_cycles_per_inst"] = (c["GRBM_GUI_ACTIVE"] / 8.0) * SIMDS / c["SQ_INSTS_VALU"] if c.get("SQ_INSTS_VALU") else None
+                rec["valu_issue_frac_of_measured_peak"] = 2.5 / rec["valu_cycles_per_inst"] if rec.get("valu_cycles_per_inst") else None
             if c.get("SQ_THREAD_CYCLES_VALU") and c.get("SQ_ACTIVE_INST_VALU"):
                 # SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU = lanes live per VALU cycle, of 16 per quad-cycle x 4 = 64
                 rec["active_lanes"] = c["SQ_THREAD_CYCLES_VALU"] / c["SQ_INSTS_VALU"] if c.get("SQ_INSTS_VALU") else None
@@ -119,6 +125,7 @@ def main():
                "frame_ms_profiled": out["frame_ms_profiled"],
                "per_kernel": {k: {"ms": v["ms"], "hbm_bytes": v.get("hbm_bytes"), "hbm_GBps": v.get("hbm_GBps"),
                                   "valu_insts": v["counters"].get("SQ_INSTS_VALU"), "valu_issue_frac": v.get("valu_issue_frac"),
+                                  "valu_cycles_per_inst": v.get("valu_cycles_per_inst"), "valu_issue_frac_of_measured_peak": v.get("valu_issue_frac_of_measured_peak"),
                                   "active_lanes": v.get("active_lanes")} for k, v in main_k.items()},
                "source": f"rocprofv3 --kernel-trace --pmc <one counter set per pass> -- python3 bench.py --config {cfg} --steps 1 --warmup 0 ({tag}); "
                          f"clock {CLOCK_GHZ} GHz nominal, {VALU_CYCLES:.0f} cycles per wave64 VALU instruction"}
