@@ -126,7 +126,7 @@ def cpu_baseline(sc, flat):
     o = orc_py.OracleScene(flat, lib=lib)
     W, H = cam.screen_width, cam.screen_height
     # Bounded sample: sets of rows spread evenly over the image height (the same mix of cheap and expensive pixels as
-    # the whole frame).  A short calibration set sizes the measured one to about 5 s of CPU work.
+    # the whole frame).  A short calibration set sizes the measured one to about 12 s of wall time on every usable core.
     def run(first_row, n_rows, stride):
         t0 = time.perf_counter()
         o.render(cam, seed=1, threads=threads, window=(0, first_row, W, n_rows), row_stride=stride, want_u8=False, want_sig=False)
@@ -134,7 +134,7 @@ def cpu_baseline(sc, flat):
     cal_rows = min(H, max(threads, 8))
     cal_stride = max(1, H // cal_rows)
     t_cal = run(0, cal_rows, cal_stride)
-    rows = int(min(H - cal_rows, max(cal_rows, cal_rows * 5.0 / max(t_cal, 1e-3))))
+    rows = int(min(H - cal_rows, max(cal_rows, cal_rows * 12.0 / max(t_cal, 1e-3))))
     rows = max(threads, rows - rows % max(1, threads))
     stride = max(1, H // rows)
     rows = min(rows, H // stride)
