@@ -745,12 +745,54 @@ extern "C" int mi_scene_upload(mi_ctx* c, const mi_scene_desc* d) {
             }
         }
     }
+    // sample_hemisphere's rotation Basis3::between_vectors(unit_y, n) (materials.rs:176) as a matrix, for the two normals a list Triangle or Plane can
+    // present to a ray (its stored normal and the negation: RayHit::new, tracing.rs:118-123; Plane: geometry.rs:476-478): the same f32 operations in the same order as
+    // pt_kernels.hip rotate_from_unit_y performs per scatter (this file is compiled with -ffp-contract=off; sqrtf and the divisions are
+    // correctly rounded on both sides, rcp_exact IS 1.0f / x), so reading the table is exact.  12 floats per entry:
+    // {c0.xyz, c1.x}{c1.yz, c2.xy}{c2.z, 1 = identity (the function returns `dir` untouched), 0, 0}; entry 2 i + (frontface ? 0 : 1) of object i.
+    std::vector<float> obj_rot(objs.size() * 24, 0.0f);
+    {
+        auto ulps_eq = [](float a, float b) {                       // approx::ulps_eq!, f32 defaults (pt_kernels.hip ulps_eq)
+            if (fabsf(a - b) <= 1.1920929e-07f) return true;
+            if ((a < 0.0f) != (b < 0.0f)) return false;
+            int32_t ia, ib; memcpy(&ia, &a, 4); memcpy(&ib, &b, 4);
+            int32_t d = (int32_t)((uint32_t)ia - (uint32_t)ib);
+            if (d < 0) d = (int32_t)(0u - (uint32_t)d);
+            return d <= 4;
+        };
+        auto rot = [&](float nx, float ny, float nz, float* out) {
+            const float k_cos_theta = ny;
+            if (ulps_eq(k_cos_theta, 1.0f)) { out[9] = 1.0f; return; }
+            const float k = sqrtf(1.0f * ((nx * nx + ny * ny) + nz * nz));
+            float qs, qx, qz;
+            if (ulps_eq(k_cos_theta / k, -1.0f)) { qs = 0.0f; qx = 0.0f; qz = -1.0f; }
+            else {
+                const float sq = k + k_cos_theta;
+                const float cx = nz, cz = -nx;
+                const float mag = sqrtf(sq * sq + ((cx * cx + 0.0f) + cz * cz));
+                const float inv = 1.0f / mag;
+                qs = sq * inv; qx = cx * inv; qz = cz * inv;
+            }
+            const float x2 = qx + qx, z2 = qz + qz;
+            const float xx2 = x2 * qx, xz2 = x2 * qz, zz2 = z2 * qz;
+            const float sz2 = z2 * qs, sx2 = x2 * qs;
+            out[0] = 1.0f - zz2; out[1] = sz2; out[2] = xz2;                       // c0
+            out[3] = -sz2; out[4] = (1.0f - xx2) - zz2; out[5] = sx2;            // c1
+            out[6] = xz2; out[7] = -sx2; out[8] = 1.0f - xx2;                     // c2
+        };
+        for (size_t i = 0; i < objs.size(); i++) if (objs[i].kind == OBJ_TRIANGLE || objs[i].kind == OBJ_PLANE) {
+            const float* n = objs[i].f + (objs[i].kind == OBJ_TRIANGLE ? 9 : 3);       // the Triangle's stored normal / the Plane's
+            rot(n[0], n[1], n[2], &obj_rot[i * 24]);
+            rot(-n[0], -n[1], -n[2], &obj_rot[i * 24 + 12]);
+        }
+    }
     // one blob: objects | list | materials | meshes | nodes | tris | attrs | textures | texels
     auto align = [](size_t x) { return (x + 255) & ~(size_t)255; };
     size_t off_obj = 0;
     size_t off_list = align(off_obj + objs.size() * sizeof(DObject));
     size_t off_bobj = align(off_list + (list.size() + 1) * sizeof(DObject));     // +1: the loop prefetches one record ahead
-    size_t off_mat = align(off_bobj + (bobjs.size() + 1) * sizeof(DObject));
+    size_t off_rot = align(off_bobj + (bobjs.size() + 1) * sizeof(DObject));
+    size_t off_mat = align(off_rot + obj_rot.size() * 4 + 16);
     size_t off_mesh = align(off_mat + mats.size() * sizeof(DMaterial));
     size_t off_meshf = align(off_mesh + live.size() * sizeof(DMesh));
     size_t off_fnodes = align(off_meshf + livef.size() * sizeof(DMeshF));
@@ -770,6 +812,7 @@ extern "C" int mi_scene_upload(mi_ctx* c, const mi_scene_desc* d) {
     put(off_obj, objs.data(), objs.size() * sizeof(DObject));
     put(off_list, list.data(), list.size() * sizeof(DObject));
     put(off_bobj, bobjs.data(), bobjs.size() * sizeof(DObject));
+    put(off_rot, obj_rot.data(), obj_rot.size() * 4);
     put(off_mat, mats.data(), mats.size() * sizeof(DMaterial));
     put(off_mesh, live.data(), live.size() * sizeof(DMesh));
     put(off_meshf, livef.data(), livef.size() * sizeof(DMeshF));
@@ -793,6 +836,7 @@ extern "C" int mi_scene_upload(mi_ctx* c, const mi_scene_desc* d) {
     c->S.objects = (const DObject*)(b + off_obj);
     c->S.list = (const DObject*)(b + off_list);
     c->S.bobjs = (const DObject*)(b + off_bobj);
+    c->S.obj_rot = (const float*)(b + off_rot);
     c->gen_volumes = !bobjs.empty();
     c->mesh_maps = false;
     for (const DMesh& M : live) if (M.material < 0 || M.tex[4] >= 0) c->mesh_maps = true;

@@ -150,6 +150,9 @@ struct DScene {
     // boundary records of ConvexVolumes whose boundary is not the inline sphere (same record format; MESH: ref = entry of `meshes`
     // at or behind n_meshes — the table holds the Scene.objects meshes first, then the boundary-only ones)
     const PT_CONST_AS DObject*   bobjs;
+    // sample_hemisphere's rotation for the two normals of every list Triangle, hoisted to the host (mi_rt.cpp): 3 float4 per entry,
+    // entry 2 i + (frontface ? 0 : 1) of Scene.objects entry i
+    const PT_CONST_AS float*     obj_rot;
     // two-stage traversal (meshes that qualify): F-tree nodes (same 2 x float4 node format; leaf word = (first << 3) | (count - 1)
     // into ftris), the F-ordered triangles {a.xyz, tri index}{e1.xyz, 0}{e2.xyz, 0}, and the per-mesh constants
     const PT_CONST_AS float*     fnodes;

@@ -107,6 +107,9 @@
 #ifndef PT_RNG_PEEP
 #define PT_RNG_PEEP 1       // value1_2 as one funnel shift, genm11 as one fma (both exact; the rejection sampler's loop 44 -> 38 VALU); 0 for A/B: cfg2 75.3 -> 74.9 ms
 #endif
+#ifndef PT_ROT_TABLE
+#define PT_ROT_TABLE 1       // sample_hemisphere's rotation for list-Triangle hits read from the table the host computed (DScene.obj_rot); 0 for A/B
+#endif
 #ifndef PT_SEG_COUNT
 #define PT_SEG_COUNT 1      // wf_main counts its path segments (mi_last_pipeline_counts[6]); 0 only to measure what the count costs
 #endif
@@ -558,6 +561,7 @@ struct Surf {
     int   kind;
     f3 albedo, emission, brdf_diffuse;   // brdf_diffuse = albedo / PI
     float roughness, metallic, ior;
+    int rot;            // >= 0: entry of DScene.obj_rot that holds sample_hemisphere's rotation for this normal (list Triangles); -1: compute it
 };
 
 __device__ __forceinline__ void load_material(const DScene& S, int id, Surf& s) {
@@ -592,6 +596,7 @@ __device__ __forceinline__ void resolve_hit(const DScene& S, const Best& b, f3 o
     // lane hit, the inline copies are one line per entry.  tools/experiments/r04_shade_record.diff.)
     auto ob = &S.objects[b.obj];
     int kind = ob->kind;
+    s.rot = -1;
     if (MESH && (PT_PRE_ATTR ? b.tri >= 0 : kind == OBJ_MESH)) {         // Best.tri >= 0 <=> the pending hit is a mesh triangle (list hits carry tags < 0)
         int mesh_idx = pre_mesh, attr_idx = pre_attr;
         if (!PT_PRE_ATTR || mesh_idx < 0) { mesh_idx = ob->ref; attr_idx = S.meshes[mesh_idx].tri_begin + b.tri; }
@@ -660,12 +665,20 @@ __device__ __forceinline__ void resolve_hit(const DScene& S, const Best& b, f3 o
         face(normalize(hp - c), d, s.n, s.frontface);                    // geometry.rs:411
     } else if (kind == OBJ_TRIANGLE) {
         face(ld3(ob->f + 9), d, s.n, s.frontface);                       // geometry.rs:449
+#if PT_ROT_TABLE
+        s.rot = 2 * b.obj + (s.frontface ? 0 : 1);
+#endif
     } else if (kind == OBJ_PLANE) {
         // geometry.rs:476-478,487: n = signum(origin_dist) * normal
         f3 normal = ld3(ob->f + 3);
         float origin_dist = dot(o - ld3(ob->f), normal);
         float sg = (origin_dist != origin_dist) ? origin_dist : (__float_as_uint(origin_dist) >> 31 ? -1.0f : 1.0f);
         face(normal * sg, d, s.n, s.frontface);
+#if PT_ROT_TABLE
+        // s.n is the stored normal or its negation (a product with +-1 and face()'s negation are exact): entry 0 / 1 of this object
+        const bool neg = (sg < 0.0f) != (!s.frontface);
+        s.rot = (sg == sg) ? 2 * b.obj + (neg ? 1 : 0) : -1;
+#endif
     } else {                                                             // OBJ_VOLUME geometry.rs:520
         face(mk3(0.0f, 0.0f, 0.0f), d, s.n, s.frontface);
     }
@@ -1023,7 +1036,7 @@ __device__ __forceinline__ void intersect_list_masked(const DScene& S, unsigned 
 // Material::scatter (materials.rs) for the resolved surface; returns the new direction
 // and the throughput factor dot_term*brdf/pdf of tracing.rs:313-316.
 // Material::scatter proper: new direction, attenuation (`.1` of the reference's tuple), 1/pdf.
-__device__ __forceinline__ void scatter_raw(const Surf& s, f3 d, Rng& rng, f3& new_d, f3& brdf, float& inv_pdf) {
+__device__ __forceinline__ void scatter_raw(const DScene& S, const Surf& s, f3 d, Rng& rng, f3& new_d, f3& brdf, float& inv_pdf) {
     int kind = s.kind;
     bool diffuse = (kind == MAT_LAMBERTIAN);
     inv_pdf = 1.0f;
@@ -1046,6 +1059,18 @@ __device__ __forceinline__ void scatter_raw(const Surf& s, f3 d, Rng& rng, f3& n
         f3 v = rand_sphere_vec(rng);
         if (diffuse) {                                                   // sample_hemisphere :171-178
             v.y = fabsf(v.y);
+            if (s.rot >= 0) {
+                // the rotation depends on the normal alone, and a list Triangle presents one of two: its matrix was computed at upload by the
+                // same f32 operations (mi_rt.cpp obj_rot) — 3 loads from a table of a few cache lines instead of ~85 VALU instructions (two
+                // sqrt, a division, a reciprocal, two ulps_eq) in a kernel that is bound by instruction issue
+                cf4_ptr R = (cf4_ptr)S.obj_rot + 3 * s.rot;
+                const float4 r0 = R[0], r1 = R[1], r2 = R[2];
+                const f3 m = mk3((r0.x * v.x + r0.w * v.y) + r1.z * v.z,
+                                 (r0.y * v.x + r1.x * v.y) + r1.w * v.z,
+                                 (r0.z * v.x + r1.y * v.y) + r2.x * v.z);
+                const bool ident = r2.y != 0.0f;
+                new_d = mk3(ident ? v.x : m.x, ident ? v.y : m.y, ident ? v.z : m.z);
+            } else
             new_d = rotate_from_unit_y(s.n, v);
             brdf = s.brdf_diffuse;                                       // albedo / PI
             inv_pdf = 6.28318530717958647692f;                           // pdf = 1/(2*PI)
@@ -1063,9 +1088,9 @@ __device__ __forceinline__ void scatter_raw(const Surf& s, f3 d, Rng& rng, f3& n
     }
 }
 // scatter + the estimator's weight dot_term * brdf / pdf (tracing.rs:312-316)
-__device__ __forceinline__ void scatter(const Surf& s, f3 d, Rng& rng, f3& new_d, f3& weight) {
+__device__ __forceinline__ void scatter(const DScene& S, const Surf& s, f3 d, Rng& rng, f3& new_d, f3& weight) {
     f3 brdf; float inv_pdf;
-    scatter_raw(s, d, rng, new_d, brdf, inv_pdf);
+    scatter_raw(S, s, d, rng, new_d, brdf, inv_pdf);
     // tracing.rs:313
     float dot_term = (mag2(s.n) > 0.0f) ? clampf(fabsf(dot(new_d, s.n)), 0.0f, 1.0f) : 1.0f;
     float wgt = dot_term * inv_pdf;
@@ -1196,7 +1221,7 @@ __global__ __launch_bounds__(kBlock) void pt_megakernel(K1Args A) {
                 if (SIG) P.sig = sig_end_depth(P.sig);
             } else {
                 f3 nd, w;
-                scatter(s, P.d, P.rng, nd, w);                        // :312-316
+                scatter(S, s, P.d, P.rng, nd, w);                        // :312-316
                 P.o = s.p; P.d = nd;
                 P.T = mk3(P.T.x * w.x, P.T.y * w.y, P.T.z * w.z);
                 end_path = false;
@@ -1298,7 +1323,7 @@ __global__ __launch_bounds__(kBlock) void pt_phong(K1Args A) {
                 shadow_weight = (sb.t * sb.t > mag2(light - ss.p)) ? 1.0f : 0.3f;
             }
             f3 nd, brdf; float inv_pdf;
-            scatter_raw(s, d, rng, nd, brdf, inv_pdf);                   // :294 `.scatter(&hit, ray).1`
+            scatter_raw(S, s, d, rng, nd, brdf, inv_pdf);                // :294 `.scatter(&hit, ray).1`
             f3 sum = (ambient + brdf * diffuse_weight) + mk3(0.4f, 0.4f, 0.4f) * specular_weight;
             color = sum * shadow_weight;
         }
@@ -1398,7 +1423,7 @@ __global__ __launch_bounds__(kBlock) void pt_branch(K1Args A, uint32_t path_samp
                 BranchFrame& f = F[level];
                 if (f.i < path_samples) {
                     f3 nd; float inv_pdf;
-                    scatter_raw(f.s, f.d, rng, nd, f.brdf, inv_pdf);            // :312
+                    scatter_raw(S, f.s, f.d, rng, nd, f.brdf, inv_pdf);         // :312
                     f.pdf = (inv_pdf != 1.0f) ? 1.0f / (2.0f * PI) : 1.0f;      // sample_hemisphere's pdf (materials.rs:178)
                     f.dot_term = (mag2(f.s.n) > 0.0f) ? clampf(fabsf(dot(nd, f.s.n)), 0.0f, 1.0f) : 1.0f;   // :313
                     o = f.s.p; d = nd; level++;        // :314 shade_ray(&new_ray, depth + 1)
@@ -1544,7 +1569,7 @@ __global__ __launch_bounds__(kBlock, PT_MIN_WAVES) void pt_megakernel_voted(K1Ar
                             if (SIG) P.sig = sig_end_depth(P.sig);
                         } else {
                             f3 nd, w;
-                            scatter(s, P.d, P.rng, nd, w);
+                            scatter(S, s, P.d, P.rng, nd, w);
                             P.o = s.p; P.d = nd;
                             P.T = mk3(P.T.x * w.x, P.T.y * w.y, P.T.z * w.z);
                             end_path = false;
@@ -1872,7 +1897,7 @@ __global__ __launch_bounds__(kBlock, (MESH == 2 ? PT_MAIN_WAVES : (MESH == 1 ? P
                     if (SIG) P.sig = sig_end_depth(P.sig);
                 } else {
                     f3 nd, w;
-                    scatter(s, P.d, P.rng, nd, w);
+                    scatter(S, s, P.d, P.rng, nd, w);
                     P.o = s.p; P.d = nd;
                     P.T = mk3(P.T.x * w.x, P.T.y * w.y, P.T.z * w.z);
                     end_path = false;
