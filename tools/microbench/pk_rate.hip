@@ -1,5 +1,5 @@
 // Issue rate of v_pk_mul_f32 / v_pk_add_f32 against v_mul_f32 / v_add_f32 on gfx950 (is packed FP32 two results per lane and issue slot?)
-//   hipcc --offload-arch=gfx950 -O2 -o pk_rate pk_rate.hip && ./pk_rate
+//   mkdir -p _build && hipcc --offload-arch=gfx950 -O2 -o _build/pk_rate pk_rate.hip && _build/pk_rate
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef float f2 __attribute__((ext_vector_type(2)));

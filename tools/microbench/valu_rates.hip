@@ -1,5 +1,5 @@
 // Issue cost of individual VALU instructions on gfx950, wave64, eight waves per SIMD, independent chains:
-//   hipcc --offload-arch=gfx950 -O2 -o valu_rates valu_rates.hip && ./valu_rates
+//   mkdir -p _build && hipcc --offload-arch=gfx950 -O2 -o _build/valu_rates valu_rates.hip && _build/valu_rates
 // Prints ns per wave instruction per SIMD and that figure relative to v_mul_f32 (DESIGN.md section 5 quotes the table).
 #include <hip/hip_runtime.h>
 #include <cstdio>
