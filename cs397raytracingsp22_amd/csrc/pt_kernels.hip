@@ -110,6 +110,7 @@
 #ifndef PT_ROT_TABLE
 #define PT_ROT_TABLE 1       // sample_hemisphere's rotation for list-Triangle hits read from the table the host computed (DScene.obj_rot); 0 for A/B
 #endif
+#define PT_LDS_AS __attribute__((address_space(3)))
 #ifndef PT_SEG_COUNT
 #define PT_SEG_COUNT 1      // wf_main counts its path segments (mi_last_pipeline_counts[6]); 0 only to measure what the count costs
 #endif
@@ -2306,7 +2307,10 @@ __global__ __launch_bounds__(BS, 8) void wf_trav_i(WfArgs A) {
         if (!PAIR) for (int k = threadIdx.x; k < nn; k += BS) k1_lds[k] = gi[k];
         else {
             float* w = (float*)k1_lds;
-            auto link = [](float f) { const int l = __float_as_int(f); return __int_as_float(l >= 0 ? l * kPairStride : l); };
+            // links to interior records become ABSOLUTE LDS addresses (the image's own LDS offset added here, once): a step then reads at
+            // `link + axis offset` through an address-space-3 pointer made from the integer, with no base to add (one VALU instruction per step)
+            const int lds0 = (int)(uint32_t)(uintptr_t)(PT_LDS_AS char*)k1_lds;
+            auto link = [lds0](float f) { const int l = __float_as_int(f); return __int_as_float(l >= 0 ? lds0 + l * kPairStride : l); };
             for (int k = threadIdx.x; k < (int)A.R.lds_nodes; k += BS) {
                 const float4 a = gi[2 * k], b = gi[2 * k + 1];
                 float* r = w + k * (kPairStride / 4);
@@ -2322,9 +2326,10 @@ __global__ __launch_bounds__(BS, 8) void wf_trav_i(WfArgs A) {
             if (!PAIR) for (int k = threadIdx.x; k < nl; k += BS) k1_lds[nn + k] = gl[k];
             else {
                 float4* ll = (float4*)((char*)k1_lds + pair_leaf_base);
+                const int lds0 = (int)(uint32_t)(uintptr_t)(PT_LDS_AS char*)k1_lds;
                 for (int k = threadIdx.x; k < nl; k += BS) {
                     float4 v = gl[k];
-                    if (k % 3 == 0) { const int l = __float_as_int(v.w); v.w = __int_as_float(l >= 0 ? l * kPairStride : l); }   // the link to the next node
+                    if (k % 3 == 0) { const int l = __float_as_int(v.w); v.w = __int_as_float(l >= 0 ? lds0 + l * kPairStride : l); }   // the link to the next node
                     ll[k] = v;
                 }
             }
@@ -2367,8 +2372,12 @@ __global__ __launch_bounds__(BS, 8) void wf_trav_i(WfArgs A) {
     float2 px = make_float2(0.0f, 0.0f), py = px, pz = px; int2 plk = make_int2(0, 0);
     int sx = 0, sy = 16, sz = 32;
     auto pair_load = [&]() {
-        px = *(const float2*)(PB + (id + sx)); py = *(const float2*)(PB + (id + sy)); pz = *(const float2*)(PB + (id + sz));
-        plk = *(const int2*)(PB + (id + 48));
+        typedef float vf2 __attribute__((ext_vector_type(2)));
+        typedef int vi2 __attribute__((ext_vector_type(2)));
+        const vf2 ax = *(const PT_LDS_AS vf2*)(uintptr_t)(uint32_t)(id + sx), ay = *(const PT_LDS_AS vf2*)(uintptr_t)(uint32_t)(id + sy),
+                  az = *(const PT_LDS_AS vf2*)(uintptr_t)(uint32_t)(id + sz);
+        const vi2 al = *(const PT_LDS_AS vi2*)(uintptr_t)(uint32_t)(id + 48);
+        px = make_float2(ax.x, ax.y); py = make_float2(ay.x, ay.y); pz = make_float2(az.x, az.y); plk = make_int2(al.x, al.y);
     };
     auto pair_signs = [&]() { sx = tinv.x < 0.0f ? 8 : 0; sy = tinv.y < 0.0f ? 24 : 16; sz = tinv.z < 0.0f ? 40 : 32; };   // geometry.rs:60 `if inv_d < 0.0`
 
