@@ -2304,8 +2304,16 @@ __global__ __launch_bounds__(BS, 8) void wf_trav_i(WfArgs A) {
     {
         cf4_ptr gi = (cf4_ptr)S.inodes;
         const int nn = (int)A.R.lds_nodes * 2;
-        if (!PAIR) for (int k = threadIdx.x; k < nn; k += BS) k1_lds[k] = gi[k];
-        else {
+        if (!PAIR) {
+            // links to interior records as ABSOLUTE LDS addresses (as in the paired layout below): a step reads `link` and `link + 16` directly
+            const int lds0 = (int)(uint32_t)(uintptr_t)(PT_LDS_AS char*)k1_lds;
+            for (int k = threadIdx.x; k < nn; k += BS) {
+                float4 v = gi[k];
+                const int l = __float_as_int(v.w);
+                v.w = __int_as_float(l >= 0 ? lds0 + l * 32 : l);
+                k1_lds[k] = v;
+            }
+        } else {
             float* w = (float*)k1_lds;
             // links to interior records become ABSOLUTE LDS addresses (the image's own LDS offset added here, once): a step then reads at
             // `link + axis offset` through an address-space-3 pointer made from the integer, with no base to add (one VALU instruction per step)
@@ -2323,8 +2331,14 @@ __global__ __launch_bounds__(BS, 8) void wf_trav_i(WfArgs A) {
         if (LEAF_LDS) {
             cf4_ptr gl = (cf4_ptr)S.lnodes;
             const int nl = (int)A.R.lds_tris * 3;                    // float4 slots of the staged leaf records
-            if (!PAIR) for (int k = threadIdx.x; k < nl; k += BS) k1_lds[nn + k] = gl[k];
-            else {
+            if (!PAIR) {
+                const int lds0 = (int)(uint32_t)(uintptr_t)(PT_LDS_AS char*)k1_lds;
+                for (int k = threadIdx.x; k < nl; k += BS) {
+                    float4 v = gl[k];
+                    if (k % 3 == 0) { const int l = __float_as_int(v.w); v.w = __int_as_float(l >= 0 ? lds0 + l * 32 : l); }   // the link to the next node
+                    k1_lds[nn + k] = v;
+                }
+            } else {
                 float4* ll = (float4*)((char*)k1_lds + pair_leaf_base);
                 const int lds0 = (int)(uint32_t)(uintptr_t)(PT_LDS_AS char*)k1_lds;
                 for (int k = threadIdx.x; k < nl; k += BS) {
@@ -2339,6 +2353,7 @@ __global__ __launch_bounds__(BS, 8) void wf_trav_i(WfArgs A) {
         __syncthreads();
     }
     const float4* IN = k1_lds;
+    const int lds0_abs = (int)(uint32_t)(uintptr_t)(PT_LDS_AS char*)k1_lds;
     const float4* LL = PAIR ? (const float4*)((const char*)k1_lds + pair_leaf_base) : k1_lds + (int)A.R.lds_nodes * 2;   // LEAF_LDS: the leaf records
     const char* PB = (const char*)k1_lds;                            // PAIR: interior records by byte offset
     // (Round 4, measured negative: the LDS image in two planes — all first halves, then all second halves, so that a 16-byte read of
@@ -2347,8 +2362,11 @@ __global__ __launch_bounds__(BS, 8) void wf_trav_i(WfArgs A) {
     // address is one more VALU per node fetch (+3.7 % instructions) and the kernel got SLOWER by what the instructions cost: cfg4 184.6 ->
     // 190.1 ms, cfg2 25.05 -> 25.90 ms, HEAD 34.8 -> 35.8 ms.  The walkers are bound by instruction issue; the conflicts are hidden
     // behind it.  tools/experiments/r04_lds_planar.diff)
-#define IN0(i) IN[2 * (i)]
-#define IN1(i) IN[2 * (i) + 1]
+    typedef float vf4 __attribute__((ext_vector_type(4)));
+    auto lds4 = [](int addr) { const vf4 v = *(const PT_LDS_AS vf4*)(uintptr_t)(uint32_t)addr; return make_float4(v.x, v.y, v.z, v.w); };
+#define IN0(a) lds4(a)               // `a`: the record's absolute LDS address (what the staged links hold)
+#define IN1(a) lds4((a) + 16)
+#define IN1_AT(i) IN[2 * (i) + 1]    // by record index: the root, whose id comes from the mesh record
     cf4_ptr LN = (cf4_ptr)S.lnodes;
     Bvh<false> B;                                                    // mesh ROOT boxes come from the ordinary node pool (enter_next_mesh)
     bvh_bind(B, S, 0);
@@ -2390,7 +2408,7 @@ __global__ __launch_bounds__(BS, 8) void wf_trav_i(WfArgs A) {
         for (int k = 0; k < 16; k++) m0[k] = M->inv_transform[k];
         B.node(M->node_begin, r0, r1);
         root0 = M->i_root; obj0 = M->object_index; tb0 = M->tri_begin;
-        if (root0 >= 0) root0 = PAIR ? *(const int*)(PB + (root0 * kPairStride + 52)) : __float_as_int(IN1(root0).w);   // the node a ray stands on after a passed root test
+        if (root0 >= 0) root0 = PAIR ? *(const int*)(PB + (root0 * kPairStride + 52)) : __float_as_int(IN1_AT(root0).w);   // the node a ray stands on after a passed root test
     }
     // the ray has passed (or skipped, for a root that is a leaf) mesh tm's root test: stand on the first node to visit
     auto start_mesh = [&]() {
@@ -2398,7 +2416,7 @@ __global__ __launch_bounds__(BS, 8) void wf_trav_i(WfArgs A) {
         if (!MULTI) { id = root0; if (id >= 0) { if (PAIR) pair_load(); else { c0 = IN0(id); c1 = IN1(id); } } tbt = t_max; tbtri = -1; tbu = tbv = 0.0f; return; }
         const int root = S.meshes[tm].i_root;
         id = root;
-        if (root >= 0) { id = PAIR ? *(const int*)(PB + (root * kPairStride + 52)) : __float_as_int(IN1(root).w); }   // root box passed with bound t_max: its left child
+        if (root >= 0) { id = PAIR ? *(const int*)(PB + (root * kPairStride + 52)) : __float_as_int(IN1_AT(root).w); }   // root box passed with bound t_max: its left child
         if (id >= 0) { if (PAIR) pair_load(); else { c0 = IN0(id); c1 = IN1(id); } }
         tbt = t_max; tbtri = -1; tbu = tbv = 0.0f;
     };
@@ -2497,6 +2515,7 @@ __global__ __launch_bounds__(BS, 8) void wf_trav_i(WfArgs A) {
                     const int ltri = __float_as_int(l1.w);
                     tbt = ok ? t : tbt; tbtri = ok ? ltri : tbtri; tbu = ok ? u : tbu; tbv = ok ? v : tbv;
                     id = __float_as_int(l0.w);
+                    if (!PAIR && !LEAF_LDS && id >= 0) id = lds0_abs + id * 32;            // a leaf record read from global memory carries a node id
                     if (id >= 0) { if (PAIR) pair_load(); else { c0 = IN0(id); c1 = IN1(id); } }
                 }
             }
@@ -2535,6 +2554,7 @@ __global__ __launch_bounds__(BS, 8) void wf_trav_i(WfArgs A) {
 
 #undef IN0
 #undef IN1
+#undef IN1_AT
 
 // ---------------------------------------------------------------- exact two-stage mesh traversal
 // For meshes whose file order makes the reference's index-range tree useless (obj/sphere.obj: 3800 box tests and 960
