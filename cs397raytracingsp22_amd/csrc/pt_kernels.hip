@@ -111,6 +111,10 @@
 #define PT_ROT_TABLE 1       // sample_hemisphere's rotation for list-Triangle hits read from the table the host computed (DScene.obj_rot); 0 for A/B
 #endif
 #define PT_LDS_AS __attribute__((address_space(3)))
+#ifndef PT_TRAVI_MED3
+#define PT_TRAVI_MED3 1      // wf_trav_i (32-byte records, one mesh): the clamped box test for waves whose rays all have finite non-zero 1/d; 0 for A/B
+                            // (cfg4 walker 188.5 -> 177.7 ms; in the MULTI forms it costs more than it saves: HEAD 35.1 -> 36.0 ms)
+#endif
 #ifndef PT_SEG_COUNT
 #define PT_SEG_COUNT 1      // wf_main counts its path segments (mi_last_pipeline_counts[6]); 0 only to measure what the count costs
 #endif
@@ -425,6 +429,28 @@ __device__ __forceinline__ bool slab_nf(float2 x, float2 y, float2 z, f3 o, f3 i
     { const float ta = (y.x - o.y) * inv_d.y, tb = (y.y - o.y) * inv_d.y; tmin = fmaxf(ta, tmin); tmax = fminf(tb, tmax); }
     { const float ta = (z.x - o.z) * inv_d.z, tb = (z.y - o.z) * inv_d.z; tmin = fmaxf(ta, tmin); tmax = fminf(tb, tmax); }
     return !(tmax <= tmin);
+}
+
+// The same decision in 4 instructions fewer, for rays whose three 1/d are finite and non-zero (`slab_plain_ray`).  Per axis the reference
+// raises tmin to the near plane and lowers tmax to the far plane; v_med3_f32 CLAMPS each of them into [near, far] instead (med3(t0, t1, x) =
+// clamp(x, min(t0, t1), max(t0, t1)); no sign select: for such a ray min / max of t0, t1 ARE its near / far values).  Write (a, b) for the
+// clamped pair and (a_r, b_r) for the reference's.  While a <= far and b >= near the two pairs stay EQUAL (clamp(a) = max(a, near),
+// clamp(b) = min(b, far)).  The first axis where that fails — a > far or b < near — is an axis where the reference pair enters the miss state
+// b_r <= a_r and the clamped pair becomes equal (both far, or both near): a miss as well.  A pair in the miss state stays there: the
+// reference's a_r only rises and b_r only falls, and a clamp is monotone, so b <= a implies clamp(b) <= clamp(a).  Hence `tmax <= tmin` after
+// the third axis is the same boolean, flat boxes (near = far) included.  A NaN product (0 * inf, only when some 1/d is infinite) would break
+// it, which is why a wave holding a ray with a non-finite or zero 1/d takes the reference form (tests/test_gpu_walkers.py axis-aligned rays).
+__device__ __forceinline__ bool slab_med3(f3 bmin, f3 bmax, f3 o, f3 inv_d, float t_min, float t_max) {
+    float tmin = t_min, tmax = t_max;
+    { const float t0 = (bmin.x - o.x) * inv_d.x, t1 = (bmax.x - o.x) * inv_d.x; tmin = __builtin_amdgcn_fmed3f(t0, t1, tmin); tmax = __builtin_amdgcn_fmed3f(t0, t1, tmax); }
+    { const float t0 = (bmin.y - o.y) * inv_d.y, t1 = (bmax.y - o.y) * inv_d.y; tmin = __builtin_amdgcn_fmed3f(t0, t1, tmin); tmax = __builtin_amdgcn_fmed3f(t0, t1, tmax); }
+    { const float t0 = (bmin.z - o.z) * inv_d.z, t1 = (bmax.z - o.z) * inv_d.z; tmin = __builtin_amdgcn_fmed3f(t0, t1, tmin); tmax = __builtin_amdgcn_fmed3f(t0, t1, tmax); }
+    return !(tmax <= tmin);
+}
+__device__ __forceinline__ bool slab_plain_ray(f3 inv_d) {
+    const float ax = fabsf(inv_d.x), ay = fabsf(inv_d.y), az = fabsf(inv_d.z);
+    const float big = __uint_as_float(0x7f800000u);
+    return (ax > 0.0f) & (ax < big) & (ay > 0.0f) & (ay < big) & (az > 0.0f) & (az < big);
 }
 
 // (Negative result, round 1: storing nodes axis-paired so that the subtract/multiply become v_pk_add_f32 /
@@ -2411,8 +2437,10 @@ __global__ __launch_bounds__(BS, 8) void wf_trav_i(WfArgs A) {
         if (root0 >= 0) root0 = PAIR ? *(const int*)(PB + (root0 * kPairStride + 52)) : __float_as_int(IN1_AT(root0).w);   // the node a ray stands on after a passed root test
     }
     // the ray has passed (or skipped, for a root that is a leaf) mesh tm's root test: stand on the first node to visit
+    bool texo = false;               // this lane's ray has a zero or non-finite 1/d: its wave takes the reference form of the box test
     auto start_mesh = [&]() {
         if (PAIR) pair_signs();
+        if (!PAIR && !MULTI && PT_TRAVI_MED3) texo = !slab_plain_ray(tinv);
         if (!MULTI) { id = root0; if (id >= 0) { if (PAIR) pair_load(); else { c0 = IN0(id); c1 = IN1(id); } } tbt = t_max; tbtri = -1; tbu = tbv = 0.0f; return; }
         const int root = S.meshes[tm].i_root;
         id = root;
@@ -2489,6 +2517,26 @@ __global__ __launch_bounds__(BS, 8) void wf_trav_i(WfArgs A) {
                         on = id >= 0;
                         if (on) pair_load();
                     }
+                }
+            } else if (PT_TRAVI_MED3 && !MULTI && __builtin_amdgcn_ballot_w64(have & texo) == 0ull) {
+                // every ray of the wave has finite non-zero 1/d (practically always): the clamped form of the box test, 6 v_med3 for 6 v_cndmask + 4 min / max
+#pragma unroll
+                for (int j = 0; j < (LEAF_LDS ? PT_TRAVL_BURST : PT_TRAVI_BURST); j++) {
+                    const bool act = have & (id >= 0);
+                    const bool hit = slab_med3(mk3(c0.x, c0.y, c0.z), mk3(c1.x, c1.y, c1.z), too, tinv, t_min, tbt);
+                    const int nxt = hit ? __float_as_int(c1.w) : __float_as_int(c0.w);
+                    id = act ? nxt : id;
+                    if (act & (id >= 0)) { c0 = IN0(id); c1 = IN1(id); }
+                }
+            } else if (PT_TRAVI_MED3 && !MULTI) {
+                // a ray with a zero or infinite 1/d is in the wave: the reference form, as a ROLLED loop (rare; keeps the kernel small)
+#pragma nounroll
+                for (int j = 0; j < (LEAF_LDS ? PT_TRAVL_BURST : PT_TRAVI_BURST); j++) {
+                    const bool act = have & (id >= 0);
+                    const bool hit = slab(mk3(c0.x, c0.y, c0.z), mk3(c1.x, c1.y, c1.z), too, tinv, t_min, tbt);      // geometry.rs:103
+                    const int nxt = hit ? __float_as_int(c1.w) : __float_as_int(c0.w);
+                    id = act ? nxt : id;
+                    if (act & (id >= 0)) { c0 = IN0(id); c1 = IN1(id); }
                 }
             } else {
                 // (the nested form of the paired layout's burst, tried on the 32-byte records too: cfg4 walker 186.1 -> 186.7 ms, HEAD unchanged)
