@@ -114,3 +114,33 @@ def test_axis_aligned_rays_through_meshes(orc, mode):
     _, _, rsig, _ = orc.OracleScene(flat).render(sc.camera, seed=21)
     _, sig = render_with_mode(mode, flat, sc.camera, 21)
     assert int((sig != rsig).sum()) == 0, f"walker mode {mode}: paths differ from the oracle"
+
+
+@pytest.mark.parametrize("mode", [4, 5, 6])
+def test_axis_aligned_rays_through_one_mesh(orc, mode):
+    """The same rays against ONE mesh: the single-mesh forms of wf_trav_i over 32-byte records (modes 4 and 5) test boxes with the clamped
+    form (slab_med3) and must send a wave that holds a ray with a zero direction component through the reference form instead — here every
+    camera ray is such a ray, and the mirror cube returns some of them along the axis.  Mode 6 (paired records) has no such split."""
+    from test_oracle_kat import cube_mesh
+    from cs397raytracingsp22_amd import Metal
+    sc = scenes.config1(96, 64, 8, 6)                                      # the Cornell box without the teapot
+    sc.camera.projection_mode = abi.MI_PROJ_ORTHOGRAPHIC
+    sc.camera.view_dir = (0.0, 0.0, -1.0)
+    sc.objects.append(StaticMesh(cube_mesh(-0.6, 0.6), Metal(albedo=(0.9, 0.9, 0.9), roughness=0.0), [None] * 5, cgmath.from_translation((0.25, 2.0, 0.5))))
+    flat = sc.flatten()
+    _, _, rsig, _ = orc.OracleScene(flat).render(sc.camera, seed=23)
+    _, sig = render_with_mode(mode, flat, sc.camera, 23)
+    assert int((sig != rsig).sum()) == 0, f"walker mode {mode}: paths differ from the oracle"
+
+
+def test_clamped_box_test_on_the_drone_with_grazing_and_axis_parallel_rays(orc):
+    """cfg4's tree through its default walker (mode 4, one mesh: the clamped box test) under an orthographic camera along -x: every camera ray
+    has two zero direction components (the reference form, rolled loop), the bounce rays have none (the clamped form) - both inside one render."""
+    sc = scenes.config4(80, 56, 8, 6, tex_size=32)
+    sc.camera.projection_mode = abi.MI_PROJ_ORTHOGRAPHIC
+    sc.camera.view_dir = (-1.0, 0.0, 0.0)
+    sc.camera.up = (0.0, 1.0, 0.0)
+    flat = sc.flatten()
+    _, _, rsig, _ = orc.OracleScene(flat).render(sc.camera, seed=5)
+    f32, sig = render_with_env({}, flat, sc.camera, 5)
+    assert int((sig != rsig).sum()) == 0
