@@ -1264,7 +1264,12 @@ static int render_tiles_wavefront(mi_ctx* c, const K1Args& k, const mi_camera_de
     // left for images beyond 156 KB whose interior nodes still fit
     int trav_lds_mode = 0;
     if (ref_nodes > 0 && !c->tune.global_bvh) {
-        if (pair_bytes <= 40u * 1024u) trav_lds_mode = 6;           // four 512-thread blocks per CU = 8 waves per SIMD
+        // one mesh to walk: the single-mesh forms over 32-byte records test boxes with the clamped form (slab_med3), 22 VALU per step like the
+        // paired layout's, on half the LDS and eight 256-thread blocks per CU (cfg2 walker 22.4 against 22.8 ms); several small meshes: the
+        // paired layout (the MULTI forms have no register left for the clamped form's class test)
+        const bool one_mesh = ref_mask == 1u && c->S.n_meshes <= 32;
+        if (one_mesh && split_bytes <= 64u * 1024u) trav_lds_mode = 5;
+        else if (pair_bytes <= 40u * 1024u) trav_lds_mode = 6;      // four 512-thread blocks per CU = 8 waves per SIMD
         else if (split_bytes <= 64u * 1024u) trav_lds_mode = 5;     // (= node_bytes: both images hold every node once and every triangle once)
         else if (node_bytes <= 64u * 1024u) trav_lds_mode = 2;
         else if (inode_bytes <= 78u * 1024u) trav_lds_mode = 4;

@@ -1,7 +1,8 @@
 """Every storage mode of the reference-tree walker gives the same paths: BVH in global memory (0), whole image in LDS with 256-thread
 blocks (2) or one 1024-thread block per CU (3), and wf_trav_i — interior nodes in LDS, leaves from global memory, two 1024-thread
 blocks per CU (4: what trees of 64 .. 150 KB such as obj/drone.obj take by default), with the leaf records in LDS too (5: trees whose whole
-split image fits 64 KB), or that with the interior records in the paired {near, far} layout (6: the default for trees up to 40 KB, the teapot).  The mode is a developer knob read once in
+split image fits 64 KB), or that with the interior records in the paired {near, far} layout (6: the default for SEVERAL small trees; one small tree - the
+teapot - takes mode 5, whose single-mesh form tests boxes with the clamped v_med3 form).  The mode is a developer knob read once in
 mi_ctx_create (MI_RT_WF_TRAV_LDS), so each mode gets a context of its own; signatures must equal the oracle's bit for bit."""
 import os
 
