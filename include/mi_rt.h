@@ -189,8 +189,8 @@ typedef struct mi_render_opts {
     uint64_t max_state_bytes;   /* wavefront pipeline: upper bound on the HBM it may hold for path state and
                                  * sample slots (0 = what renders the frame in ONE batch, at most 60 % of the free HBM: a
                                  * whole 1080p / 256 spp frame is 110 GB).  A smaller budget means more, smaller sample
-                                 * batches: same image, bit for bit, lower throughput (cfg2, round 4: one batch 77.4 ms;
-                                 * 64 / 32 / 16 / 8 / 4 GB: +2 / +7 / +14 / +25 / +46 %: DESIGN.md section 4).
+                                 * batches: same image, bit for bit, lower throughput (cfg2, round 4: one batch 72.7 ms;
+                                 * 64 / 32 / 16 / 8 / 4 GB: +1 / +8 / +13 / +24 / +43 %: DESIGN.md section 4).
                                  * The smallest batch is one sample of every pixel of the rank (about 210 B per pixel, 280 B
                                  * with a two-stage mesh): a non-zero budget below that is MI_ERR_INVALID, never silently exceeded */
 } mi_render_opts;               /* 32 bytes */
